@@ -1,0 +1,184 @@
+/*
+ * hevcrecon.h — C ABI of the MI355X picture-reconstruction engine.
+ *
+ * The engine replaces, inside an otherwise unchanged HM 9.1 decoder, the
+ * sample-domain half of decoding: de-quantisation + inverse transform, inter
+ * motion compensation, intra prediction + residual add, deblocking and SAO.
+ * Bitstream parsing (CABAC, MV derivation, DPB management) stays in the host
+ * decoder; it hands the engine the per-CTU syntax arrays it has just parsed.
+ *
+ * The reference has no plugin interface: the boundary is four C++ call sites.
+ * Each entry point below names the reference call it stands in for
+ * (paths relative to source/Lib of the reference tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure;
+ *     hevcrecon_last_error() returns a message for the last failure.
+ *   - the caller owns all host buffers; the engine copies what it needs during
+ *     the call and owns all device memory.
+ *   - a context is used from one thread at a time.  Work is queued on the
+ *     context's HIP stream; hevcrecon_picture_download() and
+ *     hevcrecon_synchronize() are the synchronisation points.
+ *   - pictures are named by small non-negative integers chosen by the caller
+ *     (the decoder uses one id per TComPic buffer it recycles).
+ */
+#ifndef HEVCRECON_H
+#define HEVCRECON_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEVCRECON_MAX_REFS 16
+#define HEVCRECON_PARTS_PER_CTU 256 /* 64x64 CTU in 4x4 partitions, z-order */
+
+typedef struct hevcrecon_ctx hevcrecon_ctx;       /* one engine instance on one GPU */
+typedef struct hevcrecon_syntax hevcrecon_syntax; /* packed syntax of one picture (host staging + HBM copy) */
+
+/* Sequence-level parameters: what TDecTop::xActivateParameterSets
+ * (TLibDecoder/TDecTop.cpp:264-293) hands to m_cSAO.create / m_cLoopFilter.create,
+ * plus the globals g_bitDepthY/C, g_uiMaxCUWidth, g_uiMaxCUDepth (TLibCommon/TComRom.cpp:93-96,362-363)
+ * that the reference reads everywhere on the path. */
+typedef struct hevcrecon_seq_params {
+  int32_t width;                  /* luma samples, multiple of 8 */
+  int32_t height;
+  int32_t bit_depth_luma;         /* 8..12 */
+  int32_t bit_depth_chroma;
+  int32_t ctu_size;               /* 64 */
+  int32_t max_cu_depth;           /* g_uiMaxCUDepth incl. g_uiAddCUDepth: ctu_size >> max_cu_depth == 4 */
+  int32_t strong_intra_smoothing; /* sps->getUseStrongIntraSmoothing() */
+  int32_t reserved[9];
+} hevcrecon_seq_params;
+
+/* Picture/slice-level parameters (one slice per picture).
+ * Sources: TComSlice getters used by TDecCu.cpp:616-625,772-781 (chroma QP offsets),
+ * TComLoopFilter.cpp:371,569-570,769 (deblocking), TDecGop.cpp:192-196 (SAO enables),
+ * TComSlice::getRefPic / getRefPOC (reference lists). */
+typedef struct hevcrecon_pic_params {
+  int32_t poc;
+  int32_t slice_type;             /* 0 = B, 1 = P, 2 = I  (TLibCommon/TypeDef.h:379-384) */
+  int32_t deblocking_disable;
+  int32_t beta_offset_div2;
+  int32_t tc_offset_div2;
+  int32_t cb_qp_offset_pps;
+  int32_t cr_qp_offset_pps;
+  int32_t cb_qp_delta_slice;
+  int32_t cr_qp_delta_slice;
+  int32_t sao_luma;               /* slice SAO enables; 0 when the SPS has SAO off */
+  int32_t sao_chroma;
+  int32_t num_ref[2];
+  int32_t ref_pic_id[2][HEVCRECON_MAX_REFS]; /* engine picture ids of the reference pictures */
+  int32_t ref_poc[2][HEVCRECON_MAX_REFS];
+} hevcrecon_pic_params;
+
+/* One CTU's parsed syntax: plain pointers to the TComDataCU member arrays
+ * (TLibCommon/TComDataCU.h:122-204), HEVCRECON_PARTS_PER_CTU entries each, z-order.
+ * mv[l] points at TComMv[256] viewed as int16 pairs (hor, ver) (TLibCommon/TComMv.h:51-55).
+ * coeff[c] are the TCoeff (int32) arrays, 4096 luma / 1024 per chroma component,
+ * z-order block offset 16*absPartIdx (4*absPartIdx chroma), raster inside a TU.
+ * sao_* are this CTU's entries of SAOParam::saoLcuParam[c][addr] (TLibCommon/TypeDef.h:342-352),
+ * merge flags already resolved by the parser; sao_type -1 = off. */
+typedef struct hevcrecon_ctu_syntax {
+  const uint8_t *depth;
+  const int8_t  *pred_mode;       /* 0 inter, 1 intra, 15 none (outside picture) */
+  const int8_t  *part_size;
+  const uint8_t *tr_idx;
+  const uint8_t *cbf[3];
+  const int8_t  *qp;
+  const uint8_t *luma_dir;
+  const uint8_t *chroma_dir;
+  const uint8_t *transform_skip[3];
+  const int16_t *mv[2];
+  const int8_t  *ref_idx[2];
+  const uint8_t *transquant_bypass; /* may be NULL */
+  const uint8_t *ipcm;              /* may be NULL */
+  const int32_t *coeff[3];
+  int32_t sao_type[3];
+  int32_t sao_subtype[3];
+  int32_t sao_offset[3][4];
+} hevcrecon_ctu_syntax;
+
+/* ---- context ---------------------------------------------------------- */
+
+/* Creates an engine on HIP device `device`.  Fails (non-zero, *out = NULL) when no GPU is present. */
+int hevcrecon_create(hevcrecon_ctx **out, int device);
+void hevcrecon_destroy(hevcrecon_ctx *ctx);
+const char *hevcrecon_last_error(const hevcrecon_ctx *ctx);
+
+/* Replaces m_cSAO.create / m_cLoopFilter.create in TDecTop::xActivateParameterSets
+ * (TLibDecoder/TDecTop.cpp:290-292).  Idempotent when the parameters are unchanged
+ * (the reference calls its counterpart once per slice). */
+int hevcrecon_sequence_init(hevcrecon_ctx *ctx, const hevcrecon_seq_params *sp);
+
+/* ---- per-picture syntax ------------------------------------------------ */
+
+int hevcrecon_syntax_create(hevcrecon_ctx *ctx, hevcrecon_syntax **out);
+void hevcrecon_syntax_destroy(hevcrecon_syntax *syn);
+
+/* Start a new picture in `syn` (drops whatever it held).  Stands where TDecTop::xDecodeSlice
+ * obtains the picture buffer for a first slice (TLibDecoder/TDecTop.cpp:358-376). */
+int hevcrecon_syntax_begin(hevcrecon_syntax *syn);
+
+/* Replaces the call m_pcCuDecoder->decompressCU(pcCU) in TDecSlice::decompressSlice
+ * (TLibDecoder/TDecSlice.cpp:367): instead of reconstructing the CTU at once, its syntax
+ * is packed into the picture's work lists.  CTUs must arrive in coding (raster) order.
+ * Must be called before TComPic::compressMotion (TLibDecoder/TDecGop.cpp:210) sub-samples the MVs. */
+int hevcrecon_syntax_add_ctu(hevcrecon_syntax *syn, int ctu_addr, const hevcrecon_ctu_syntax *ctu);
+
+/* Closes the picture and queues the host-to-device copy of the packed syntax. */
+int hevcrecon_syntax_finish(hevcrecon_syntax *syn, const hevcrecon_pic_params *pp);
+
+/* ---- reconstruction ---------------------------------------------------- */
+
+/* Replaces, for one picture, every decompressCU of its CTUs (TLibDecoder/TDecCu.cpp:142,404-466)
+ * followed by TComLoopFilter::loopFilterPic (TLibDecoder/TDecGop.cpp:181) and
+ * TComSampleAdaptiveOffset::SAOProcess (TLibDecoder/TDecGop.cpp:199).  The result is picture
+ * `dst_pic_id` (created or overwritten), resident on the device and usable as a reference.
+ * Reads only device memory; asynchronous. */
+int hevcrecon_reconstruct(hevcrecon_ctx *ctx, hevcrecon_syntax *syn, int dst_pic_id);
+
+/* Same for `n` mutually independent pictures (different streams, or pictures of one
+ * stream none of which references another) with one set of kernel launches. */
+int hevcrecon_reconstruct_batch(hevcrecon_ctx *ctx, int n, hevcrecon_syntax *const *syn, const int *dst_pic_ids);
+
+/* Copies the final picture into TComPicYuv-style planes (Pel = int16; strides in samples)
+ * so that calcAndPrintHashStatus (TLibDecoder/TDecGop.cpp:235) and TVideoIOYuv::write keep working.
+ * Blocks until the picture is complete. */
+int hevcrecon_picture_download(hevcrecon_ctx *ctx, int pic_id, int16_t *y, int16_t *cb, int16_t *cr,
+                               int stride_y, int stride_c);
+
+/* Intermediate planes of the most recent hevcrecon_reconstruct on this context, for stage-level
+ * parity checks: stage 0 = before deblocking, 1 = after deblocking (before SAO). */
+int hevcrecon_debug_download_stage(hevcrecon_ctx *ctx, int stage, int16_t *y, int16_t *cb, int16_t *cr,
+                                   int stride_y, int stride_c);
+
+/* Uploads host planes as picture `pic_id` (tests, and concealment of a lost reference:
+ * TDecTop::xCreateLostPicture, TLibDecoder/TDecTop.cpp:214-261). */
+int hevcrecon_picture_upload(hevcrecon_ctx *ctx, int pic_id, int poc, const int16_t *y, const int16_t *cb,
+                             const int16_t *cr, int stride_y, int stride_c);
+
+/* Frees the device picture (TComPic buffers being destroyed: TLibDecoder/TDecTop.cpp:98-118). */
+int hevcrecon_picture_release(hevcrecon_ctx *ctx, int pic_id);
+
+int hevcrecon_synchronize(hevcrecon_ctx *ctx);
+
+/* ---- measurement ------------------------------------------------------- */
+
+/* Per-kernel GPU time, measured with HIP events on the context's stream while profiling is on.
+ * Kernel indices: see hevcrecon_kernel_name(). */
+#define HEVCRECON_NUM_KERNELS 8
+int hevcrecon_profile_enable(hevcrecon_ctx *ctx, int on);
+int hevcrecon_profile_read(hevcrecon_ctx *ctx, double ms_out[HEVCRECON_NUM_KERNELS],
+                           int64_t launches_out[HEVCRECON_NUM_KERNELS]);
+const char *hevcrecon_kernel_name(int idx);
+
+/* Algorithmic bytes of one picture as packed in `syn`:
+ * S*b*(1 + 2 + 2*[SAO on]) + MC reads (w*h*3/2*b per reference used) + 2*coded coefficients + 16*(W/4)*(H/4). */
+int64_t hevcrecon_syntax_algorithmic_bytes(const hevcrecon_syntax *syn);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEVCRECON_H */

@@ -1,0 +1,346 @@
+// hm_bridge.cpp — glue between the reference decoder (HM 9.1) and the reconstruction engine's C ABI.
+//
+// TEST INFRASTRUCTURE.  This file is compiled together with the reference's own
+// sources (from where they lie, never copied) into oracle/_ref/TAppDecoderBridge.
+// It takes over four reference call sites WITHOUT editing reference source: the build
+// renames the reference's definitions with -D macros (see oracle/Makefile) and this
+// file supplies the symbols the rest of the decoder links against:
+//
+//   TDecCu::decompressCU            TLibDecoder/TDecSlice.cpp:367   (per-CTU reconstruction)
+//   TComLoopFilter::loopFilterPic   TLibDecoder/TDecGop.cpp:181     (deblocking)
+//   TComSampleAdaptiveOffset::SAOProcess  TLibDecoder/TDecGop.cpp:199 (SAO)
+//   TComPic::compressMotion         TLibDecoder/TDecGop.cpp:210     (observation point only)
+//
+// Modes (environment variable HEVCRECON_MODE):
+//   unset / "ref"  : behave exactly like the reference.
+//   "dump"         : run the reference, and write every picture's parsed syntax plus MD5s of
+//                    the picture before deblocking / after deblocking / final to
+//                    $HEVCRECON_DUMP (golden-vector generator).  HEVCRECON_DUMP_PLANES=1 adds
+//                    the three stage pictures themselves.
+//   "engine"       : the reference parses only; reconstruction, deblocking and SAO run in the
+//                    engine loaded from $HEVCRECON_LIB (libhevcrecon.so) and the final picture
+//                    is copied back into TComPicYuv, so the reference's own MD5 check, output
+//                    writer and DPB logic keep working unchanged.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+#include <dlfcn.h>
+
+// Declare both the renamed reference definition (xxx_ref) and the symbol this file supplies (xxx)
+// inside the reference's own class declarations.
+#define decompressCU decompressCU_ref(TComDataCU *pcCU); Void decompressCU
+#define loopFilterPic loopFilterPic_ref(TComPic *pcPic); Void loopFilterPic
+#define SAOProcess SAOProcess_ref(SAOParam *pcSaoParam); Void SAOProcess
+#define compressMotion compressMotion_ref(); Void compressMotion
+#include "TLibDecoder/TDecCu.h"
+#include "TLibCommon/TComLoopFilter.h"
+#include "TLibCommon/TComSampleAdaptiveOffset.h"
+#include "TLibCommon/TComPic.h"
+#undef decompressCU
+#undef loopFilterPic
+#undef SAOProcess
+#undef compressMotion
+#include "libmd5/MD5.h"
+
+#include "../include/hevcrecon.h"
+
+namespace {
+
+enum Mode { MODE_REF, MODE_DUMP, MODE_ENGINE };
+
+struct EngineApi {
+  void *lib;
+  int (*create)(hevcrecon_ctx **, int);
+  const char *(*last_error)(const hevcrecon_ctx *);
+  int (*sequence_init)(hevcrecon_ctx *, const hevcrecon_seq_params *);
+  int (*syntax_create)(hevcrecon_ctx *, hevcrecon_syntax **);
+  int (*syntax_begin)(hevcrecon_syntax *);
+  int (*syntax_add_ctu)(hevcrecon_syntax *, int, const hevcrecon_ctu_syntax *);
+  int (*syntax_finish)(hevcrecon_syntax *, const hevcrecon_pic_params *);
+  int (*reconstruct)(hevcrecon_ctx *, hevcrecon_syntax *, int);
+  int (*picture_download)(hevcrecon_ctx *, int, int16_t *, int16_t *, int16_t *, int, int);
+};
+
+struct Bridge {
+  Mode mode;
+  FILE *dump;
+  bool dump_planes;
+  bool header_written;
+  std::map<TComPic *, int> pic_ids;
+  EngineApi api;
+  hevcrecon_ctx *ctx;
+  hevcrecon_syntax *syn;
+  unsigned char stage_md5[3][3][16];
+  std::vector<uint16_t> stage_planes[3];
+  Bridge() : mode(MODE_REF), dump(NULL), dump_planes(false), header_written(false), ctx(NULL), syn(NULL) {
+    const char *m = getenv("HEVCRECON_MODE");
+    if (m && !strcmp(m, "dump")) {
+      mode = MODE_DUMP;
+      const char *path = getenv("HEVCRECON_DUMP");
+      dump = fopen(path ? path : "hevcrecon.syn", "wb");
+      if (!dump) { perror("HEVCRECON_DUMP"); exit(EXIT_FAILURE); }
+      dump_planes = getenv("HEVCRECON_DUMP_PLANES") && atoi(getenv("HEVCRECON_DUMP_PLANES"));
+    } else if (m && !strcmp(m, "engine")) {
+      mode = MODE_ENGINE;
+      load_engine();
+    }
+  }
+  ~Bridge() { if (dump) fclose(dump); }
+
+  void fail(const char *what) {
+    fprintf(stderr, "hm_bridge: %s: %s\n", what, (ctx && api.last_error) ? api.last_error(ctx) : "");
+    exit(EXIT_FAILURE);
+  }
+  template <class F> void sym(F &f, const char *name) {
+    f = (F)dlsym(api.lib, name);
+    if (!f) { fprintf(stderr, "hm_bridge: missing symbol %s\n", name); exit(EXIT_FAILURE); }
+  }
+  void load_engine() {
+    const char *path = getenv("HEVCRECON_LIB");
+    api.lib = dlopen(path ? path : "libhevcrecon.so", RTLD_NOW);
+    if (!api.lib) { fprintf(stderr, "hm_bridge: %s\n", dlerror()); exit(EXIT_FAILURE); }
+    sym(api.create, "hevcrecon_create");
+    sym(api.last_error, "hevcrecon_last_error");
+    sym(api.sequence_init, "hevcrecon_sequence_init");
+    sym(api.syntax_create, "hevcrecon_syntax_create");
+    sym(api.syntax_begin, "hevcrecon_syntax_begin");
+    sym(api.syntax_add_ctu, "hevcrecon_syntax_add_ctu");
+    sym(api.syntax_finish, "hevcrecon_syntax_finish");
+    sym(api.reconstruct, "hevcrecon_reconstruct");
+    sym(api.picture_download, "hevcrecon_picture_download");
+    if (api.create(&ctx, 0)) fail("hevcrecon_create");
+    if (api.syntax_create(ctx, &syn)) fail("hevcrecon_syntax_create");
+  }
+
+  int pic_id(TComPic *p) {
+    std::map<TComPic *, int>::iterator it = pic_ids.find(p);
+    if (it != pic_ids.end()) return it->second;
+    int id = (int)pic_ids.size();
+    pic_ids[p] = id;
+    return id;
+  }
+
+  void fill_seq(TComPic *pic, hevcrecon_seq_params &sp) {
+    TComSlice *sl = pic->getSlice(pic->getCurrSliceIdx());
+    memset(&sp, 0, sizeof(sp));
+    sp.width = sl->getSPS()->getPicWidthInLumaSamples();
+    sp.height = sl->getSPS()->getPicHeightInLumaSamples();
+    sp.bit_depth_luma = g_bitDepthY;
+    sp.bit_depth_chroma = g_bitDepthC;
+    sp.ctu_size = g_uiMaxCUWidth;
+    sp.max_cu_depth = g_uiMaxCUDepth;
+    sp.strong_intra_smoothing = sl->getSPS()->getUseStrongIntraSmoothing();
+  }
+
+  void fill_pic(TComPic *pic, hevcrecon_pic_params &pp) {
+    TComSlice *sl = pic->getSlice(pic->getCurrSliceIdx());
+    memset(&pp, 0, sizeof(pp));
+    pp.poc = sl->getPOC();
+    pp.slice_type = (int)sl->getSliceType();
+    pp.deblocking_disable = sl->getDeblockingFilterDisable();
+    pp.beta_offset_div2 = sl->getDeblockingFilterBetaOffsetDiv2();
+    pp.tc_offset_div2 = sl->getDeblockingFilterTcOffsetDiv2();
+    pp.cb_qp_offset_pps = sl->getPPS()->getChromaCbQpOffset();
+    pp.cr_qp_offset_pps = sl->getPPS()->getChromaCrQpOffset();
+    pp.cb_qp_delta_slice = sl->getSliceQpDeltaCb();
+    pp.cr_qp_delta_slice = sl->getSliceQpDeltaCr();
+    bool sao = sl->getSPS()->getUseSAO();
+    pp.sao_luma = sao && sl->getSaoEnabledFlag();
+    pp.sao_chroma = sao && sl->getSaoEnabledFlagChroma();
+    for (int l = 0; l < 2; l++) {
+      pp.num_ref[l] = sl->isIntra() ? 0 : sl->getNumRefIdx(RefPicList(l));
+      if (l == 1 && !sl->isInterB()) pp.num_ref[l] = 0;
+      for (int i = 0; i < pp.num_ref[l] && i < HEVCRECON_MAX_REFS; i++) {
+        pp.ref_pic_id[l][i] = pic_id(sl->getRefPic(RefPicList(l), i));
+        pp.ref_poc[l][i] = sl->getRefPic(RefPicList(l), i)->getPOC();
+      }
+    }
+  }
+
+  void fill_ctu(TComPic *pic, int addr, const hevcrecon_pic_params &pp, hevcrecon_ctu_syntax &cs, int8_t *refbuf) {
+    TComDataCU *cu = pic->getCU(addr);
+    memset(&cs, 0, sizeof(cs));
+    cs.depth = cu->getDepth();
+    cs.pred_mode = (const int8_t *)cu->getPredictionMode();
+    cs.part_size = (const int8_t *)cu->getPartitionSize();
+    cs.tr_idx = cu->getTransformIdx();
+    cs.qp = (const int8_t *)cu->getQP();
+    cs.luma_dir = cu->getLumaIntraDir();
+    cs.chroma_dir = cu->getChromaIntraDir();
+    cs.transquant_bypass = (const uint8_t *)cu->getCUTransquantBypass();
+    cs.ipcm = (const uint8_t *)cu->getIPCMFlag();
+    const TextType tt[3] = {TEXT_LUMA, TEXT_CHROMA_U, TEXT_CHROMA_V};
+    for (int c = 0; c < 3; c++) {
+      cs.cbf[c] = cu->getCbf(tt[c]);
+      cs.transform_skip[c] = cu->getTransformSkip(tt[c]);
+    }
+    cs.coeff[0] = cu->getCoeffY();
+    cs.coeff[1] = cu->getCoeffCb();
+    cs.coeff[2] = cu->getCoeffCr();
+    for (int l = 0; l < 2; l++) {
+      TComCUMvField *f = cu->getCUMvField(RefPicList(l));
+      cs.mv[l] = (const int16_t *)&f->getMv(0);
+      for (int i = 0; i < HEVCRECON_PARTS_PER_CTU; i++) refbuf[l * HEVCRECON_PARTS_PER_CTU + i] = (int8_t)f->getRefIdx(i);
+      cs.ref_idx[l] = refbuf + l * HEVCRECON_PARTS_PER_CTU;
+    }
+    SAOParam *sao = pic->getPicSym()->getSaoParam();
+    for (int c = 0; c < 3; c++) {
+      bool on = c == 0 ? pp.sao_luma : pp.sao_chroma;
+      cs.sao_type[c] = -1;
+      if (on && sao && sao->saoLcuParam[c]) {
+        const SaoLcuParam &p = sao->saoLcuParam[c][addr];
+        cs.sao_type[c] = p.typeIdx;
+        cs.sao_subtype[c] = p.subTypeIdx;
+        for (int i = 0; i < 4; i++) cs.sao_offset[c][i] = p.typeIdx >= 0 ? p.offset[i] : 0;
+      }
+    }
+  }
+
+  // MD5 with the byte convention of calcMD5 (TLibCommon/TComPicYuvMD5.cpp:188-213).
+  void capture_stage(TComPic *pic, int stage) {
+    TComPicYuv *yuv = pic->getPicYuvRec();
+    int w = yuv->getWidth(), h = yuv->getHeight();
+    if (dump_planes) stage_planes[stage].clear();
+    for (int c = 0; c < 3; c++) {
+      Pel *p = c == 0 ? yuv->getLumaAddr() : c == 1 ? yuv->getCbAddr() : yuv->getCrAddr();
+      int stride = c == 0 ? yuv->getStride() : yuv->getCStride();
+      int pw = c == 0 ? w : w / 2, ph = c == 0 ? h : h / 2;
+      int bd = c == 0 ? g_bitDepthY : g_bitDepthC;
+      MD5 md5;
+      std::vector<unsigned char> row(pw * 2);
+      for (int y = 0; y < ph; y++) {
+        int n = 0;
+        for (int x = 0; x < pw; x++) {
+          Pel v = p[y * stride + x];
+          row[n++] = (unsigned char)(v & 0xff);
+          if (bd > 8) row[n++] = (unsigned char)(v >> 8);
+          if (dump_planes) stage_planes[stage].push_back((uint16_t)v);
+        }
+        md5.update(&row[0], n);
+      }
+      md5.finalize(stage_md5[stage][c]);
+    }
+  }
+
+  template <class T> void put(const T *p, size_t n) { fwrite(p, sizeof(T), n, dump); }
+
+  void write_picture(TComPic *pic) {
+    hevcrecon_seq_params sp;
+    fill_seq(pic, sp);
+    if (!header_written) {
+      fwrite("HVSYN1\0\0", 1, 8, dump);
+      put(&sp, 1);
+      header_written = true;
+    }
+    hevcrecon_pic_params pp;
+    fill_pic(pic, pp);
+    int nctu = pic->getNumCUsInFrame();
+    int32_t hdr[4] = {0x54434950 /* "PICT" */, nctu, pic_id(pic), dump_planes ? 1 : 0};
+    put(hdr, 4);
+    put(&pp, 1);
+    std::vector<hevcrecon_ctu_syntax> cs(nctu);
+    std::vector<int8_t> refbuf(nctu * 2 * HEVCRECON_PARTS_PER_CTU);
+    for (int a = 0; a < nctu; a++) fill_ctu(pic, a, pp, cs[a], &refbuf[a * 2 * HEVCRECON_PARTS_PER_CTU]);
+    const int P = HEVCRECON_PARTS_PER_CTU;
+    for (int a = 0; a < nctu; a++) put(cs[a].depth, P);
+    for (int a = 0; a < nctu; a++) put(cs[a].pred_mode, P);
+    for (int a = 0; a < nctu; a++) put(cs[a].part_size, P);
+    for (int a = 0; a < nctu; a++) put(cs[a].tr_idx, P);
+    for (int c = 0; c < 3; c++) for (int a = 0; a < nctu; a++) put(cs[a].cbf[c], P);
+    for (int a = 0; a < nctu; a++) put(cs[a].qp, P);
+    for (int a = 0; a < nctu; a++) put(cs[a].luma_dir, P);
+    for (int a = 0; a < nctu; a++) put(cs[a].chroma_dir, P);
+    for (int c = 0; c < 3; c++) for (int a = 0; a < nctu; a++) put(cs[a].transform_skip[c], P);
+    for (int l = 0; l < 2; l++) for (int a = 0; a < nctu; a++) put(cs[a].mv[l], 2 * P);
+    for (int l = 0; l < 2; l++) for (int a = 0; a < nctu; a++) put(cs[a].ref_idx[l], P);
+    for (int a = 0; a < nctu; a++) put(cs[a].transquant_bypass, P);
+    for (int a = 0; a < nctu; a++) put(cs[a].ipcm, P);
+    std::vector<int16_t> c16;
+    for (int c = 0; c < 3; c++) {
+      int n = c == 0 ? 16 * P : 4 * P;
+      c16.resize(n);
+      for (int a = 0; a < nctu; a++) {
+        for (int i = 0; i < n; i++) {
+          int32_t v = cs[a].coeff[c][i];
+          c16[i] = (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v);
+        }
+        put(&c16[0], n);
+      }
+    }
+    for (int a = 0; a < nctu; a++) {
+      int32_t s[18];
+      for (int c = 0; c < 3; c++) {
+        s[c * 6 + 0] = cs[a].sao_type[c];
+        s[c * 6 + 1] = cs[a].sao_subtype[c];
+        for (int i = 0; i < 4; i++) s[c * 6 + 2 + i] = cs[a].sao_offset[c][i];
+      }
+      put(s, 18);
+    }
+    fwrite(stage_md5, 1, sizeof(stage_md5), dump);
+    if (dump_planes)
+      for (int s = 0; s < 3; s++) put(&stage_planes[s][0], stage_planes[s].size());
+    fflush(dump);
+  }
+
+  void engine_picture(TComPic *pic) {
+    hevcrecon_seq_params sp;
+    fill_seq(pic, sp);
+    if (api.sequence_init(ctx, &sp)) fail("hevcrecon_sequence_init");
+    hevcrecon_pic_params pp;
+    fill_pic(pic, pp);
+    if (api.syntax_begin(syn)) fail("hevcrecon_syntax_begin");
+    int nctu = pic->getNumCUsInFrame();
+    for (int a = 0; a < nctu; a++) {
+      hevcrecon_ctu_syntax cs;
+      int8_t refbuf[2 * HEVCRECON_PARTS_PER_CTU];
+      fill_ctu(pic, a, pp, cs, refbuf);
+      if (api.syntax_add_ctu(syn, a, &cs)) fail("hevcrecon_syntax_add_ctu");
+    }
+    if (api.syntax_finish(syn, &pp)) fail("hevcrecon_syntax_finish");
+    int id = pic_id(pic);
+    if (api.reconstruct(ctx, syn, id)) fail("hevcrecon_reconstruct");
+    TComPicYuv *yuv = pic->getPicYuvRec();
+    if (api.picture_download(ctx, id, yuv->getLumaAddr(), yuv->getCbAddr(), yuv->getCrAddr(), yuv->getStride(),
+                             yuv->getCStride()))
+      fail("hevcrecon_picture_download");
+  }
+};
+
+Bridge &bridge() {
+  static Bridge b;
+  return b;
+}
+
+}  // namespace
+
+Void TDecCu::decompressCU(TComDataCU *pcCU) {
+  if (bridge().mode == MODE_ENGINE) return;  // reconstruction is deferred to the engine
+  decompressCU_ref(pcCU);
+}
+
+Void TComLoopFilter::loopFilterPic(TComPic *pcPic) {
+  Bridge &b = bridge();
+  if (b.mode == MODE_ENGINE) {
+    b.engine_picture(pcPic);
+    return;
+  }
+  if (b.mode == MODE_DUMP) b.capture_stage(pcPic, 0);
+  loopFilterPic_ref(pcPic);
+  if (b.mode == MODE_DUMP) b.capture_stage(pcPic, 1);
+}
+
+Void TComSampleAdaptiveOffset::SAOProcess(SAOParam *pcSaoParam) {
+  if (bridge().mode == MODE_ENGINE) return;  // already applied by the engine
+  SAOProcess_ref(pcSaoParam);
+}
+
+Void TComPic::compressMotion() {
+  Bridge &b = bridge();
+  if (b.mode == MODE_DUMP) {
+    b.capture_stage(this, 2);
+    b.write_picture(this);  // before the motion field is sub-sampled
+  }
+  compressMotion_ref();
+}
