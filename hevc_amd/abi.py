@@ -79,6 +79,8 @@ EXPORTS = {
     "hevcrecon_last_error": (C.c_char_p, [_P]),
     "hevcrecon_sequence_init": (C.c_int, [_P, C.POINTER(SeqParams)]),
     "hevcrecon_syntax_create": (C.c_int, [_P, C.POINTER(_P)]),
+    "hevcrecon_syntax_create_detached": (C.c_int, [C.POINTER(SeqParams), C.POINTER(_P)]),
+    "hevcrecon_syntax_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "hevcrecon_syntax_destroy": (None, [_P]),
     "hevcrecon_syntax_begin": (C.c_int, [_P]),
     "hevcrecon_syntax_add_ctu": (C.c_int, [_P, C.c_int, C.POINTER(CtuSyntax)]),
@@ -86,6 +88,7 @@ EXPORTS = {
     "hevcrecon_reconstruct": (C.c_int, [_P, _P, C.c_int]),
     "hevcrecon_reconstruct_batch": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int)]),
     "hevcrecon_picture_download": (C.c_int, [_P, C.c_int, _I16P, _I16P, _I16P, C.c_int, C.c_int]),
+    "hevcrecon_debug_keep_stages": (C.c_int, [_P, C.c_int]),
     "hevcrecon_debug_download_stage": (C.c_int, [_P, C.c_int, _I16P, _I16P, _I16P, C.c_int, C.c_int]),
     "hevcrecon_picture_upload": (C.c_int, [_P, C.c_int, C.c_int, _I16P, _I16P, _I16P, C.c_int, C.c_int]),
     "hevcrecon_picture_release": (C.c_int, [_P, C.c_int]),

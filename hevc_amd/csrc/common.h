@@ -1,0 +1,114 @@
+// common.h — data layout shared by the host packer and the gfx950 kernels.
+//
+// Everything a picture needs lives in HBM in five flat arrays, written once by the host packer
+// (packer.cpp) and read by every kernel:
+//   * Part4   rec4[(H/4)*(W/4)]  one 16-byte record per 4x4 luma block, RASTER order over the picture
+//                                (the reference keeps these per CTU in z-order: TLibCommon/TComDataCU.h:122-204)
+//   * TuItem  tu[4][...]         one entry per coded transform block, grouped by size 4/8/16/32
+//   * int16   coeff[...]         coded coefficients, raster inside a block, blocks back to back
+//   * IntraItem intra[...]       one entry per intra prediction block, sorted by dependency level
+//   * SaoCtu  sao[nCtu*3]        SAO parameters per CTU and component
+// Sample planes are uint8 for 8-bit sequences and uint16 otherwise, with no margin: kernels clamp
+// reference coordinates instead of reading the reference's 80-sample replicated border.
+#ifndef HEVCRECON_COMMON_H
+#define HEVCRECON_COMMON_H
+
+#include <stdint.h>
+
+#define HR_MAX_REFS 16
+#define HR_MAX_BATCH 64
+
+// Part4.flags
+#define P4_DEPTH_MASK 0x03
+#define P4_INTRA 0x04
+#define P4_PARTSIZE_SHIFT 3 /* 3 bits */
+#define P4_BYPASS 0x40
+#define P4_IPCM 0x80
+// Part4.tu
+#define P4_TRIDX_MASK 0x03
+#define P4_CBF_Y 0x04 /* luma cbf at the leaf transform depth */
+#define P4_VALID 0x20 /* inside the picture */
+
+struct __attribute__((aligned(16))) Part4 {
+  uint8_t flags;
+  uint8_t tu;
+  int8_t qp;
+  uint8_t pad;
+  int8_t ref_idx[2];
+  uint8_t pad2[2];
+  int16_t mv[2][2]; /* [list][hor, ver], quarter luma samples, exactly as parsed (unused lists too) */
+};
+
+// TuItem.flags
+#define TU_TSKIP 0x01
+#define TU_DST 0x02
+#define TU_TO_RESI 0x04 /* intra block: write the residual to the residual buffer, else add it to the picture */
+#define TU_BYPASS 0x08
+
+struct TuItem {
+  uint16_t x, y;     /* block position in its component plane */
+  uint8_t comp;      /* 0 Y, 1 Cb, 2 Cr */
+  uint8_t flags;
+  int8_t qp;         /* luma QP of the coding unit */
+  uint8_t pad;
+  uint32_t coeff_off; /* index of the block's first coefficient in coeff[] (and of its residual in resi[]) */
+};
+
+#define IN_CORNER 0x01
+#define IN_HAS_RESI 0x02
+
+struct IntraItem {
+  uint16_t x, y;       /* block position in its component plane */
+  uint8_t log2n;       /* 2..5 */
+  uint8_t comp;
+  uint8_t mode;        /* 0 planar, 1 DC, 2..34 angular (chroma DM already resolved) */
+  uint8_t flags;
+  uint16_t avail_left; /* bit j: unit j of the left column, from the top; units [n/u, 2n/u) are below-left */
+  uint16_t avail_above; /* bit i: unit i of the row above, from the left; units [n/u, 2n/u) are above-right */
+  uint32_t resi_off;
+};
+
+struct SaoCtu {
+  int8_t type; /* -1 off, 0..3 edge classes, 4 band */
+  int8_t band; /* band position */
+  int8_t offset[4];
+  int8_t pad[2];
+};
+
+struct SeqInfo {
+  int32_t w, h, cw, ch;
+  int32_t uw, uh; /* picture size in 4x4 units */
+  int32_t ctus_w, ctus_h;
+  int32_t bd_y, bd_c;
+  int32_t strong_intra;
+  int32_t stride_y, stride_c; /* plane strides in samples */
+};
+
+// Per-picture job descriptor, read by every kernel through a device array indexed by the
+// picture's position in the batch.
+struct PicJob {
+  void *rec[3];                       /* working picture: prediction, reconstruction, deblocking in place */
+  void *out[3];                       /* final picture (DPB entry), written by SAO */
+  const void *ref[2][HR_MAX_REFS][3]; /* reference pictures (final planes) */
+  int32_t ref_poc[2][HR_MAX_REFS];
+  const Part4 *rec4;
+  const TuItem *tu[4];
+  int32_t n_tu[4];
+  const int16_t *coeff;
+  int16_t *resi;
+  const IntraItem *intra;
+  const int32_t *level_off; /* n_levels + 1 entries */
+  int32_t n_levels;
+  const SaoCtu *sao;
+  int32_t slice_type; /* 0 B, 1 P, 2 I */
+  int32_t deblock_disable, beta_off_div2, tc_off_div2;
+  int32_t cb_off_pps, cr_off_pps; /* deblocking uses the PPS offsets only */
+  int32_t cb_off, cr_off;         /* PPS offset + slice delta, for de-quantisation */
+  int32_t sao_luma, sao_chroma;
+  int32_t *error_flag;
+};
+
+// Kernel classes for the per-kernel timers (hevcrecon_profile_read).
+enum { K_INTER = 0, K_TRANSFORM, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_COPY, K_OTHER, K_COUNT };
+
+#endif

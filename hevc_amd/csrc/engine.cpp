@@ -1,0 +1,696 @@
+// engine.cpp — the C ABI of include/hevcrecon.h: device pictures (DPB), per-picture syntax objects
+// (host packer + HBM copy), and the launch sequence that reconstructs a batch of pictures.
+//
+// Launch sequence per batch (one HIP stream, in order):
+//   k_inter  ->  k_transform x4 sizes  ->  k_intra x levels  ->  k_deblock V  ->  k_deblock H  ->  k_sao
+// Inter prediction goes first because intra blocks of P/B pictures read their inter neighbours'
+// reconstruction; availability for intra is decided by the packer from coding order, not by what
+// happens to be in memory, so reconstructing inter blocks early cannot change results.
+#ifdef HEVCRECON_EMULATE
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/hevcrecon.h"
+#include "common.h"
+#include "kernels.h"
+#include "packer.h"
+
+namespace {
+const int kMaxPics = 1 << 16;
+const int kRing = 16;
+
+struct DevPicture {
+  void *base = nullptr;
+  void *p[3] = {nullptr, nullptr, nullptr};
+  int poc = 0;
+  bool valid = false;
+};
+
+struct Interval {
+  int kind;
+  hipEvent_t a, b;
+};
+}  // namespace
+
+struct hevcrecon_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool have_seq = false;
+  hevcrecon_seq_params sp;
+  SeqInfo si;
+  int pel_bytes = 1;
+  size_t plane_off[3] = {0, 0, 0}, pic_bytes = 0;
+  std::vector<DevPicture> pics;
+  std::vector<DevPicture> work;
+  DevPicture stage[2];
+  bool keep_stages = false;
+  PicJob *jobs_host = nullptr;  // pinned ring: kRing slots of HR_MAX_BATCH jobs
+  PicJob *jobs_dev = nullptr;
+  hipEvent_t ring_ev[kRing];
+  bool ring_used[kRing];
+  int ring_pos = 0;
+  int32_t *error_flag_dev = nullptr;
+  void *dl_host = nullptr;  // pinned staging for downloads / uploads
+  size_t dl_cap = 0;
+  bool profiling = false;
+  std::vector<Interval> intervals;
+  std::vector<hipEvent_t> event_pool;
+  double ms[K_COUNT];
+  int64_t launches[K_COUNT];
+  std::string err;
+};
+
+struct hevcrecon_syntax {
+  hevcrecon_ctx *ctx = nullptr;  // NULL for a detached (host-only) object
+  PackedPicture pk;
+  SeqInfo si;
+  char *dev = nullptr;
+  size_t dev_cap = 0;
+  char *host = nullptr;  // pinned staging
+  size_t host_cap = 0;
+  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_resi = 0, off_intra = 0, off_level = 0, off_sao = 0;
+  bool uploaded = false;
+  std::string err;
+};
+
+namespace {
+
+int fail(hevcrecon_ctx *c, const std::string &m) {
+  if (c) c->err = m;
+  return 1;
+}
+#define HIPCHK(c, call)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) return fail(c, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+SeqInfo make_seq_info(const hevcrecon_seq_params &sp) {
+  SeqInfo s;
+  s.w = sp.width;
+  s.h = sp.height;
+  s.cw = sp.width / 2;
+  s.ch = sp.height / 2;
+  s.uw = sp.width / 4;
+  s.uh = sp.height / 4;
+  s.ctus_w = (sp.width + 63) / 64;
+  s.ctus_h = (sp.height + 63) / 64;
+  s.bd_y = sp.bit_depth_luma;
+  s.bd_c = sp.bit_depth_chroma;
+  s.strong_intra = sp.strong_intra_smoothing;
+  s.stride_y = (sp.width + 127) & ~127;
+  s.stride_c = (sp.width / 2 + 127) & ~127;
+  return s;
+}
+
+bool seq_params_ok(const hevcrecon_seq_params &sp, std::string &why) {
+  if (sp.ctu_size != 64 || (sp.ctu_size >> sp.max_cu_depth) != 4) {
+    why = "only 64x64 CTUs with 4x4 minimum partitions are supported";
+    return false;
+  }
+  if (sp.width <= 0 || sp.height <= 0 || (sp.width & 7) || (sp.height & 7) || sp.width > 8192 || sp.height > 8192) {
+    why = "picture size must be a multiple of 8 and at most 8192";
+    return false;
+  }
+  if (sp.bit_depth_luma < 8 || sp.bit_depth_luma > 12 || sp.bit_depth_chroma < 8 || sp.bit_depth_chroma > 12 ||
+      (sp.bit_depth_luma > 8) != (sp.bit_depth_chroma > 8)) {
+    why = "bit depths must be 8..12 and on the same side of 8 for luma and chroma";
+    return false;
+  }
+  return true;
+}
+
+int alloc_picture(hevcrecon_ctx *c, DevPicture &p) {
+  if (p.base) return 0;
+  HIPCHK(c, hipMalloc(&p.base, c->pic_bytes));
+  for (int i = 0; i < 3; i++) p.p[i] = (char *)p.base + c->plane_off[i];
+  return 0;
+}
+void free_picture(DevPicture &p) {
+  if (p.base) hipFree(p.base);
+  p = DevPicture();
+}
+
+hipEvent_t get_event(hevcrecon_ctx *c) {
+  if (!c->event_pool.empty()) {
+    hipEvent_t e = c->event_pool.back();
+    c->event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hipEventCreate(&e);
+  return e;
+}
+
+struct Timed {
+  hevcrecon_ctx *c;
+  int kind;
+  hipEvent_t a = nullptr;
+  Timed(hevcrecon_ctx *c_, int kind_, int nlaunch) : c(c_), kind(kind_) {
+    c->launches[kind] += nlaunch;
+    if (c->profiling) {
+      a = get_event(c);
+      hipEventRecord(a, c->stream);
+    }
+  }
+  ~Timed() {
+    if (a) {
+      hipEvent_t b = get_event(c);
+      hipEventRecord(b, c->stream);
+      c->intervals.push_back(Interval{kind, a, b});
+    }
+  }
+};
+
+void drain_intervals(hevcrecon_ctx *c) {
+  for (size_t i = 0; i < c->intervals.size(); i++) {
+    Interval &iv = c->intervals[i];
+    float ms = 0;
+    hipEventSynchronize(iv.b);
+    hipEventElapsedTime(&ms, iv.a, iv.b);
+    c->ms[iv.kind] += ms;
+    c->event_pool.push_back(iv.a);
+    c->event_pool.push_back(iv.b);
+  }
+  c->intervals.clear();
+}
+
+int ensure_staging(hevcrecon_ctx *c, size_t n) {
+  if (c->dl_cap >= n) return 0;
+  if (c->dl_host) hipHostFree(c->dl_host);
+  c->dl_host = nullptr;
+  c->dl_cap = 0;
+  HIPCHK(c, hipHostMalloc(&c->dl_host, n));
+  c->dl_cap = n;
+  return 0;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Copy device planes of `p` into int16 host planes.
+int download_planes(hevcrecon_ctx *c, const DevPicture &p, int16_t *y, int16_t *cb, int16_t *cr, int stride_y, int stride_c) {
+  const SeqInfo &s = c->si;
+  const size_t pb = c->pel_bytes;
+  const size_t ny = (size_t)s.w * s.h * pb, nc = (size_t)s.cw * s.ch * pb;
+  if (ensure_staging(c, ny + 2 * nc)) return 1;
+  char *h = (char *)c->dl_host;
+  HIPCHK(c, hipMemcpy2DAsync(h, s.w * pb, p.p[0], s.stride_y * pb, s.w * pb, s.h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(h + ny, s.cw * pb, p.p[1], s.stride_c * pb, s.cw * pb, s.ch, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(h + ny + nc, s.cw * pb, p.p[2], s.stride_c * pb, s.cw * pb, s.ch, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int16_t *dst[3] = {y, cb, cr};
+  const char *src[3] = {h, h + ny, h + ny + nc};
+  for (int k = 0; k < 3; k++) {
+    const int w = k ? s.cw : s.w, hh = k ? s.ch : s.h, st = k ? stride_c : stride_y;
+    for (int r = 0; r < hh; r++) {
+      int16_t *d = dst[k] + (size_t)r * st;
+      if (pb == 1) {
+        const uint8_t *q = (const uint8_t *)src[k] + (size_t)r * w;
+        for (int i = 0; i < w; i++) d[i] = q[i];
+      } else {
+        const uint16_t *q = (const uint16_t *)src[k] + (size_t)r * w;
+        for (int i = 0; i < w; i++) d[i] = (int16_t)q[i];
+      }
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" int hevcrecon_create(hevcrecon_ctx **out, int device) {
+  if (!out) return 1;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return 2;  // no GPU: no engine
+  if (hipSetDevice(device) != hipSuccess) return 2;
+  hevcrecon_ctx *c = new hevcrecon_ctx();
+  c->device = device;
+  std::memset(&c->sp, 0, sizeof(c->sp));
+  std::memset(c->ms, 0, sizeof(c->ms));
+  std::memset(c->launches, 0, sizeof(c->launches));
+  std::memset(c->ring_used, 0, sizeof(c->ring_used));
+  bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+  ok = ok && hipHostMalloc((void **)&c->jobs_host, sizeof(PicJob) * HR_MAX_BATCH * kRing) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->jobs_dev, sizeof(PicJob) * HR_MAX_BATCH * kRing) == hipSuccess;
+  ok = ok && hipMalloc((void **)&c->error_flag_dev, 64) == hipSuccess;
+  for (int i = 0; ok && i < kRing; i++) ok = hipEventCreate(&c->ring_ev[i]) == hipSuccess;
+  if (!ok) {
+    delete c;
+    return 3;
+  }
+  hipMemsetAsync(c->error_flag_dev, 0, 64, c->stream);
+  *out = c;
+  return 0;
+}
+
+extern "C" void hevcrecon_destroy(hevcrecon_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  drain_intervals(c);
+  for (size_t i = 0; i < c->pics.size(); i++) free_picture(c->pics[i]);
+  for (size_t i = 0; i < c->work.size(); i++) free_picture(c->work[i]);
+  free_picture(c->stage[0]);
+  free_picture(c->stage[1]);
+  for (size_t i = 0; i < c->event_pool.size(); i++) hipEventDestroy(c->event_pool[i]);
+  for (int i = 0; i < kRing; i++) hipEventDestroy(c->ring_ev[i]);
+  if (c->jobs_host) hipHostFree(c->jobs_host);
+  if (c->jobs_dev) hipFree(c->jobs_dev);
+  if (c->error_flag_dev) hipFree(c->error_flag_dev);
+  if (c->dl_host) hipHostFree(c->dl_host);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" const char *hevcrecon_last_error(const hevcrecon_ctx *c) { return c ? c->err.c_str() : "no context (is a GPU present?)"; }
+
+extern "C" int hevcrecon_sequence_init(hevcrecon_ctx *c, const hevcrecon_seq_params *sp) {
+  if (!c || !sp) return 1;
+  if (c->have_seq && std::memcmp(&c->sp, sp, sizeof(*sp)) == 0) return 0;  // called once per slice by the decoder
+  std::string why;
+  if (!seq_params_ok(*sp, why)) return fail(c, why);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < c->pics.size(); i++) free_picture(c->pics[i]);
+  for (size_t i = 0; i < c->work.size(); i++) free_picture(c->work[i]);
+  free_picture(c->stage[0]);
+  free_picture(c->stage[1]);
+  c->sp = *sp;
+  c->si = make_seq_info(*sp);
+  c->pel_bytes = sp->bit_depth_luma > 8 ? 2 : 1;
+  const size_t pb = c->pel_bytes;
+  c->plane_off[0] = 0;
+  c->plane_off[1] = align_up((size_t)c->si.stride_y * c->si.h * pb, 256);
+  c->plane_off[2] = c->plane_off[1] + align_up((size_t)c->si.stride_c * c->si.ch * pb, 256);
+  c->pic_bytes = c->plane_off[2] + align_up((size_t)c->si.stride_c * c->si.ch * pb, 256);
+  c->have_seq = true;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// syntax objects
+// ---------------------------------------------------------------------------------------------
+extern "C" int hevcrecon_syntax_create(hevcrecon_ctx *c, hevcrecon_syntax **out) {
+  if (!out) return 1;
+  *out = nullptr;
+  if (!c) return 1;
+  if (!c->have_seq) return fail(c, "hevcrecon_sequence_init must come first");
+  hevcrecon_syntax *s = new hevcrecon_syntax();
+  s->ctx = c;
+  s->si = c->si;
+  *out = s;
+  return 0;
+}
+
+extern "C" int hevcrecon_syntax_create_detached(const hevcrecon_seq_params *sp, hevcrecon_syntax **out) {
+  if (!out || !sp) return 1;
+  *out = nullptr;
+  std::string why;
+  if (!seq_params_ok(*sp, why)) return 1;
+  hevcrecon_syntax *s = new hevcrecon_syntax();
+  s->si = make_seq_info(*sp);
+  *out = s;
+  return 0;
+}
+
+extern "C" void hevcrecon_syntax_destroy(hevcrecon_syntax *s) {
+  if (!s) return;
+  if (s->ctx) {
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+  }
+  if (s->dev) hipFree(s->dev);
+  if (s->host) hipHostFree(s->host);
+  delete s;
+}
+
+extern "C" int hevcrecon_syntax_begin(hevcrecon_syntax *s) {
+  if (!s) return 1;
+  if (s->ctx) {
+    if (!s->ctx->have_seq) return fail(s->ctx, "no sequence parameters");
+    s->si = s->ctx->si;
+    // the previous upload from the staging buffer must have left the host before it is rewritten
+    if (s->uploaded) hipStreamSynchronize(s->ctx->stream);
+  }
+  s->uploaded = false;
+  s->pk.begin(s->si);
+  return 0;
+}
+
+extern "C" int hevcrecon_syntax_add_ctu(hevcrecon_syntax *s, int ctu_addr, const hevcrecon_ctu_syntax *ctu) {
+  if (!s || !ctu) return 1;
+  if (!s->pk.add_ctu(ctu_addr, ctu)) {
+    s->err = s->pk.error;
+    return fail(s->ctx, s->pk.error);
+  }
+  return 0;
+}
+
+extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_params *pp) {
+  if (!s || !pp) return 1;
+  if (!s->pk.finish(pp)) {
+    s->err = s->pk.error;
+    return fail(s->ctx, s->pk.error);
+  }
+  if (!s->ctx) return 0;  // detached: host-side packing only
+  hevcrecon_ctx *c = s->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  PackedPicture &k = s->pk;
+  size_t off = 0;
+  auto place = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  s->off_rec4 = place(k.rec4.size() * sizeof(Part4));
+  for (int i = 0; i < 4; i++) s->off_tu[i] = place(k.tu[i].size() * sizeof(TuItem));
+  s->off_coeff = place(k.coeff.size() * sizeof(int16_t));
+  s->off_intra = place(k.intra.size() * sizeof(IntraItem));
+  s->off_level = place(k.level_off.size() * sizeof(int32_t));
+  s->off_sao = place(k.sao.size() * sizeof(SaoCtu));
+  const size_t upload_bytes = off;
+  s->off_resi = place(k.coeff.size() * sizeof(int16_t));  // device-only scratch, same indexing as coeff
+  const size_t total = off;
+  if (s->dev_cap < total) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (s->dev) hipFree(s->dev);
+    s->dev = nullptr;
+    s->dev_cap = 0;
+    const size_t cap = total + total / 4;
+    HIPCHK(c, hipMalloc((void **)&s->dev, cap));
+    s->dev_cap = cap;
+  }
+  if (s->host_cap < upload_bytes) {
+    if (s->host) hipHostFree(s->host);
+    s->host = nullptr;
+    s->host_cap = 0;
+    const size_t cap = upload_bytes + upload_bytes / 4;
+    HIPCHK(c, hipHostMalloc((void **)&s->host, cap));
+    s->host_cap = cap;
+  }
+  std::memcpy(s->host + s->off_rec4, k.rec4.data(), k.rec4.size() * sizeof(Part4));
+  for (int i = 0; i < 4; i++) std::memcpy(s->host + s->off_tu[i], k.tu[i].data(), k.tu[i].size() * sizeof(TuItem));
+  std::memcpy(s->host + s->off_coeff, k.coeff.data(), k.coeff.size() * sizeof(int16_t));
+  std::memcpy(s->host + s->off_intra, k.intra.data(), k.intra.size() * sizeof(IntraItem));
+  std::memcpy(s->host + s->off_level, k.level_off.data(), k.level_off.size() * sizeof(int32_t));
+  std::memcpy(s->host + s->off_sao, k.sao.data(), k.sao.size() * sizeof(SaoCtu));
+  HIPCHK(c, hipMemcpyAsync(s->dev, s->host, upload_bytes, hipMemcpyHostToDevice, c->stream));
+  s->uploaded = true;
+  return 0;
+}
+
+extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[16]) {
+  if (!s || !out) return 1;
+  const PackedPicture &k = s->pk;
+  for (int i = 0; i < 16; i++) out[i] = 0;
+  for (int i = 0; i < 4; i++) out[i] = (int64_t)k.tu[i].size();
+  out[4] = (int64_t)k.coeff.size();
+  out[5] = (int64_t)k.intra.size();
+  out[6] = k.level_off.empty() ? 0 : (int64_t)k.level_off.size() - 1;
+  out[7] = k.mc_ref_samples;
+  out[8] = (int64_t)k.rec4.size();
+  int64_t intra4 = 0;
+  for (size_t i = 0; i < k.rec4.size(); i++) intra4 += (k.rec4[i].flags & P4_INTRA) ? 1 : 0;
+  out[9] = intra4;
+  out[10] = k.finished ? 1 : 0;
+  return 0;
+}
+
+extern "C" int64_t hevcrecon_syntax_algorithmic_bytes(const hevcrecon_syntax *s) { return s ? s->pk.algorithmic_bytes() : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// reconstruction
+// ---------------------------------------------------------------------------------------------
+extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, const int *dst_ids) {
+  if (!c || !syn || !dst_ids) return 1;
+  if (n <= 0 || n > HR_MAX_BATCH) return fail(c, "batch size must be 1..64");
+  if (!c->have_seq) return fail(c, "no sequence parameters");
+  HIPCHK(c, hipSetDevice(c->device));
+  const SeqInfo &s = c->si;
+  // ---- validate everything the kernels will index with, before anything is launched ----
+  for (int i = 0; i < n; i++) {
+    hevcrecon_syntax *y = syn[i];
+    if (!y || y->ctx != c || !y->uploaded || !y->pk.finished) return fail(c, "syntax object not finished on this context");
+    if (std::memcmp(&y->si, &s, sizeof(s)) != 0) return fail(c, "syntax object packed for different sequence parameters");
+    if (dst_ids[i] < 0 || dst_ids[i] >= kMaxPics) return fail(c, "picture id out of range");
+    for (int j = 0; j < i; j++)
+      if (dst_ids[j] == dst_ids[i]) return fail(c, "duplicate destination picture in batch");
+    const hevcrecon_pic_params &pp = y->pk.pp;
+    for (int l = 0; l < 2; l++)
+      for (int r = 0; r < pp.num_ref[l]; r++) {
+        const int id = pp.ref_pic_id[l][r];
+        if (id < 0 || id >= (int)c->pics.size() || !c->pics[id].valid) return fail(c, "reference picture is not resident");
+        for (int j = 0; j < n; j++)
+          if (dst_ids[j] == id) return fail(c, "a picture of the batch references another picture of the batch");
+      }
+    if (pp.slice_type != 2) {
+      // every reference index stored in the motion records must exist in the lists
+      const std::vector<Part4> &r4 = y->pk.rec4;
+      for (size_t k = 0; k < r4.size(); k++) {
+        if (r4[k].flags & P4_INTRA) continue;
+        if (r4[k].ref_idx[0] >= pp.num_ref[0] || r4[k].ref_idx[1] >= pp.num_ref[1] || (r4[k].ref_idx[0] < 0 && r4[k].ref_idx[1] < 0))
+          return fail(c, "motion record refers to a reference index outside the lists");
+      }
+    }
+  }
+  // ---- device pictures ----
+  for (int i = 0; i < n; i++) {
+    if ((int)c->pics.size() <= dst_ids[i]) c->pics.resize(dst_ids[i] + 1);
+    if (alloc_picture(c, c->pics[dst_ids[i]])) return 1;
+  }
+  if ((int)c->work.size() < n) c->work.resize(n);
+  for (int i = 0; i < n; i++)
+    if (alloc_picture(c, c->work[i])) return 1;
+  if (c->keep_stages)
+    for (int k = 0; k < 2; k++)
+      if (alloc_picture(c, c->stage[k])) return 1;
+  // ---- job descriptors ----
+  const int slot = c->ring_pos;
+  c->ring_pos = (c->ring_pos + 1) % kRing;
+  if (c->ring_used[slot]) HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
+  PicJob *jh = c->jobs_host + (size_t)slot * HR_MAX_BATCH;
+  PicJob *jd = c->jobs_dev + (size_t)slot * HR_MAX_BATCH;
+  int max_tu[4] = {0, 0, 0, 0}, max_levels = 0;
+  bool any_inter = false, any_deblock = false;
+  for (int i = 0; i < n; i++) {
+    hevcrecon_syntax *y = syn[i];
+    const PackedPicture &k = y->pk;
+    PicJob &j = jh[i];
+    std::memset(&j, 0, sizeof(j));
+    for (int p = 0; p < 3; p++) {
+      j.rec[p] = c->work[i].p[p];
+      j.out[p] = c->pics[dst_ids[i]].p[p];
+    }
+    for (int l = 0; l < 2; l++)
+      for (int r = 0; r < k.pp.num_ref[l]; r++) {
+        const DevPicture &rp = c->pics[k.pp.ref_pic_id[l][r]];
+        for (int p = 0; p < 3; p++) j.ref[l][r][p] = rp.p[p];
+        j.ref_poc[l][r] = k.pp.ref_poc[l][r];
+      }
+    j.rec4 = (const Part4 *)(y->dev + y->off_rec4);
+    for (int t = 0; t < 4; t++) {
+      j.tu[t] = (const TuItem *)(y->dev + y->off_tu[t]);
+      j.n_tu[t] = (int)k.tu[t].size();
+      if (j.n_tu[t] > max_tu[t]) max_tu[t] = j.n_tu[t];
+    }
+    j.coeff = (const int16_t *)(y->dev + y->off_coeff);
+    j.resi = (int16_t *)(y->dev + y->off_resi);
+    j.intra = (const IntraItem *)(y->dev + y->off_intra);
+    j.level_off = (const int32_t *)(y->dev + y->off_level);
+    j.n_levels = k.level_off.empty() ? 0 : (int)k.level_off.size() - 1;
+    if (j.n_levels > max_levels) max_levels = j.n_levels;
+    j.sao = (const SaoCtu *)(y->dev + y->off_sao);
+    j.slice_type = k.pp.slice_type;
+    j.deblock_disable = k.pp.deblocking_disable;
+    j.beta_off_div2 = k.pp.beta_offset_div2;
+    j.tc_off_div2 = k.pp.tc_offset_div2;
+    j.cb_off_pps = k.pp.cb_qp_offset_pps;
+    j.cr_off_pps = k.pp.cr_qp_offset_pps;
+    j.cb_off = k.pp.cb_qp_offset_pps + k.pp.cb_qp_delta_slice;
+    j.cr_off = k.pp.cr_qp_offset_pps + k.pp.cr_qp_delta_slice;
+    j.sao_luma = k.pp.sao_luma;
+    j.sao_chroma = k.pp.sao_chroma;
+    j.error_flag = c->error_flag_dev;
+    any_inter = any_inter || k.pp.slice_type != 2;
+    any_deblock = any_deblock || !k.pp.deblocking_disable;
+  }
+  HIPCHK(c, hipMemcpyAsync(jd, jh, sizeof(PicJob) * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->ring_ev[slot], c->stream));
+  c->ring_used[slot] = true;
+  // ---- launches ----
+  if (any_inter) {
+    Timed t(c, K_INTER, 1);
+    hr_launch(K_INTER, jd, n, s, c->stream, 0, 0);
+  }
+  {
+    int nl = 0;
+    for (int t = 0; t < 4; t++) nl += max_tu[t] > 0;
+    if (nl) {
+      Timed tm(c, K_TRANSFORM, nl);
+      for (int t = 0; t < 4; t++)
+        if (max_tu[t] > 0) hr_launch(K_TRANSFORM, jd, n, s, c->stream, t + 2, max_tu[t]);
+    }
+  }
+  if (max_levels > 0) {
+    Timed tm(c, K_INTRA, 0);
+    for (int l = 0; l < max_levels; l++) {
+      int mx = 0;
+      for (int i = 0; i < n; i++) {
+        const std::vector<int32_t> &lo = syn[i]->pk.level_off;
+        if (l + 1 < (int)lo.size()) mx = std::max(mx, lo[l + 1] - lo[l]);
+      }
+      if (mx > 0) {
+        hr_launch(K_INTRA, jd, n, s, c->stream, l, mx);
+        c->launches[K_INTRA]++;
+      }
+    }
+  }
+  if (c->keep_stages) {
+    Timed tm(c, K_COPY, 1);
+    HIPCHK(c, hipMemcpyAsync(c->stage[0].base, c->work[0].base, c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (any_deblock) {
+    {
+      Timed tm(c, K_DEBLOCK_V, 1);
+      hr_launch(K_DEBLOCK_V, jd, n, s, c->stream, 0, 0);
+    }
+    {
+      Timed tm(c, K_DEBLOCK_H, 1);
+      hr_launch(K_DEBLOCK_H, jd, n, s, c->stream, 0, 0);
+    }
+  }
+  if (c->keep_stages) {
+    Timed tm(c, K_COPY, 1);
+    HIPCHK(c, hipMemcpyAsync(c->stage[1].base, c->work[0].base, c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  {
+    Timed tm(c, K_SAO, 1);
+    hr_launch(K_SAO, jd, n, s, c->stream, 0, 0);
+  }
+  HIPCHK(c, hipGetLastError());
+  for (int i = 0; i < n; i++) {
+    c->pics[dst_ids[i]].valid = true;
+    c->pics[dst_ids[i]].poc = syn[i]->pk.pp.poc;
+  }
+  if (c->intervals.size() > 4096) drain_intervals(c);
+  return 0;
+}
+
+extern "C" int hevcrecon_reconstruct(hevcrecon_ctx *c, hevcrecon_syntax *syn, int dst_pic_id) {
+  hevcrecon_syntax *one[1] = {syn};
+  return hevcrecon_reconstruct_batch(c, 1, one, &dst_pic_id);
+}
+
+extern "C" int hevcrecon_picture_download(hevcrecon_ctx *c, int pic_id, int16_t *y, int16_t *cb, int16_t *cr, int stride_y,
+                                          int stride_c) {
+  if (!c || !y || !cb || !cr) return 1;
+  if (pic_id < 0 || pic_id >= (int)c->pics.size() || !c->pics[pic_id].valid) return fail(c, "picture is not resident");
+  HIPCHK(c, hipSetDevice(c->device));
+  return download_planes(c, c->pics[pic_id], y, cb, cr, stride_y, stride_c);
+}
+
+extern "C" int hevcrecon_debug_keep_stages(hevcrecon_ctx *c, int on) {
+  if (!c) return 1;
+  c->keep_stages = on != 0;
+  return 0;
+}
+
+extern "C" int hevcrecon_debug_download_stage(hevcrecon_ctx *c, int stage, int16_t *y, int16_t *cb, int16_t *cr, int stride_y,
+                                              int stride_c) {
+  if (!c || !y || !cb || !cr || stage < 0 || stage > 1) return 1;
+  if (!c->keep_stages || !c->stage[stage].base) return fail(c, "stage pictures are kept only after hevcrecon_debug_keep_stages(ctx, 1)");
+  HIPCHK(c, hipSetDevice(c->device));
+  return download_planes(c, c->stage[stage], y, cb, cr, stride_y, stride_c);
+}
+
+extern "C" int hevcrecon_picture_upload(hevcrecon_ctx *c, int pic_id, int poc, const int16_t *y, const int16_t *cb, const int16_t *cr,
+                                        int stride_y, int stride_c) {
+  if (!c || !y || !cb || !cr) return 1;
+  if (!c->have_seq) return fail(c, "no sequence parameters");
+  if (pic_id < 0 || pic_id >= kMaxPics) return fail(c, "picture id out of range");
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((int)c->pics.size() <= pic_id) c->pics.resize(pic_id + 1);
+  DevPicture &p = c->pics[pic_id];
+  if (alloc_picture(c, p)) return 1;
+  const SeqInfo &s = c->si;
+  const size_t pb = c->pel_bytes;
+  const size_t ny = (size_t)s.w * s.h * pb, nc = (size_t)s.cw * s.ch * pb;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (ensure_staging(c, ny + 2 * nc)) return 1;
+  char *h = (char *)c->dl_host;
+  const int16_t *src[3] = {y, cb, cr};
+  char *dst[3] = {h, h + ny, h + ny + nc};
+  for (int k = 0; k < 3; k++) {
+    const int w = k ? s.cw : s.w, hh = k ? s.ch : s.h, st = k ? stride_c : stride_y;
+    for (int r = 0; r < hh; r++) {
+      const int16_t *q = src[k] + (size_t)r * st;
+      if (pb == 1) {
+        uint8_t *d = (uint8_t *)dst[k] + (size_t)r * w;
+        for (int i = 0; i < w; i++) d[i] = (uint8_t)q[i];
+      } else {
+        uint16_t *d = (uint16_t *)dst[k] + (size_t)r * w;
+        for (int i = 0; i < w; i++) d[i] = (uint16_t)q[i];
+      }
+    }
+  }
+  HIPCHK(c, hipMemcpy2DAsync(p.p[0], s.stride_y * pb, h, s.w * pb, s.w * pb, s.h, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(p.p[1], s.stride_c * pb, h + ny, s.cw * pb, s.cw * pb, s.ch, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(p.p[2], s.stride_c * pb, h + ny + nc, s.cw * pb, s.cw * pb, s.ch, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  p.valid = true;
+  p.poc = poc;
+  return 0;
+}
+
+extern "C" int hevcrecon_picture_release(hevcrecon_ctx *c, int pic_id) {
+  if (!c) return 1;
+  if (pic_id < 0 || pic_id >= (int)c->pics.size()) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  free_picture(c->pics[pic_id]);
+  return 0;
+}
+
+extern "C" int hevcrecon_synchronize(hevcrecon_ctx *c) {
+  if (!c) return 1;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// measurement
+// ---------------------------------------------------------------------------------------------
+extern "C" int hevcrecon_profile_enable(hevcrecon_ctx *c, int on) {
+  if (!c) return 1;
+  drain_intervals(c);
+  c->profiling = on != 0;
+  std::memset(c->ms, 0, sizeof(c->ms));
+  std::memset(c->launches, 0, sizeof(c->launches));
+  return 0;
+}
+
+extern "C" int hevcrecon_profile_read(hevcrecon_ctx *c, double ms_out[HEVCRECON_NUM_KERNELS], int64_t launches_out[HEVCRECON_NUM_KERNELS]) {
+  if (!c || !ms_out || !launches_out) return 1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  drain_intervals(c);
+  for (int i = 0; i < HEVCRECON_NUM_KERNELS; i++) {
+    ms_out[i] = c->ms[i];
+    launches_out[i] = c->launches[i];
+  }
+  return 0;
+}
+
+extern "C" const char *hevcrecon_kernel_name(int idx) {
+  static const char *names[K_COUNT] = {"k_inter", "k_transform", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao", "stage_copy", "other"};
+  return idx >= 0 && idx < K_COUNT ? names[idx] : "";
+}

@@ -1,0 +1,11 @@
+// kernels.h — launch interface between the engine (engine.cpp) and the kernels (kernels.hip).
+#ifndef HEVCRECON_KERNELS_H
+#define HEVCRECON_KERNELS_H
+#include "common.h"
+
+// Launches kernel class `kind` (K_* of common.h) for a batch of `n` pictures described by the device
+// array `jobs`.  arg/arg2: K_TRANSFORM: log2 block size, max blocks of that size over the batch;
+// K_INTRA: dependency level, max blocks of that level over the batch.
+void hr_launch(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t stream, int arg, int arg2);
+
+#endif

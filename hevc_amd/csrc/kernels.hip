@@ -1,0 +1,777 @@
+// kernels.hip — the gfx950 kernels of the picture-reconstruction engine.
+//
+// All arithmetic is integer and must match HM 9.1 bit for bit; each kernel cites the reference code
+// whose results it reproduces (paths relative to source/Lib of the reference).  None of it is a
+// translation: the reference walks CTU by CTU on one thread, here every kind of work runs over the
+// whole picture (and over a batch of pictures, blockIdx.y) at once:
+//
+//   k_inter      one lane per 4x4 luma block (+ its 2x2 chroma blocks): motion compensation straight
+//                from the per-4x4 motion records, no PU list
+//   k_transform  one lane per column/row of a transform block: de-quantisation + 2-D inverse
+//                transform, result added to the picture (inter) or kept as residual (intra)
+//   k_intra      one wave per intra prediction block, one launch per dependency level
+//   k_deblock    one lane per 4-sample edge segment; vertical edges, then horizontal edges
+//   k_sao        one lane per 4 samples, out of place (deblocked picture -> final picture)
+#ifdef HEVCRECON_EMULATE
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include "common.h"
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+
+template <typename pel_t>
+__device__ __forceinline__ const pel_t *plane_c(const void *p) { return (const pel_t *)p; }
+
+// Core transform matrix of the 32-point inverse DCT: entry (k, i) is round(64*sqrt(2)*cos(pi*k*(2i+1)/64)) as
+// standardised (row 0 is 64); the 16/8/4-point matrices are its rows 2k/4k/8k truncated to their first
+// 16/8/4 entries.  Built at compile time from the 32 distinct magnitudes.  (The reference holds the
+// expanded matrices in TLibCommon/TComRom.cpp:230-304.)
+struct T32Table {
+  int8_t v[32][32];
+};
+constexpr T32Table make_t32() {
+  const int mag[33] = {0, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                       61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};  // index j: angle pi*j/64
+  T32Table t = {};
+  for (int k = 0; k < 32; k++)
+    for (int i = 0; i < 32; i++) {
+      int val = 64;
+      if (k > 0) {
+        int m = (k * (2 * i + 1)) & 127;
+        if (m > 64) m = 128 - m;
+        val = m > 32 ? -mag[64 - m] : mag[m];
+      }
+      t.v[k][i] = (int8_t)val;
+    }
+  return t;
+}
+__constant__ T32Table kT32tab = make_t32();
+#define kT32 kT32tab.v
+// 4-point inverse DST used for intra luma 4x4 (TLibCommon/TComRom.cpp:316-322).
+__constant__ int8_t kDst4[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
+// chroma QP mapping (TLibCommon/TComRom.cpp:306-312)
+__constant__ uint8_t kChromaScale[58] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
+                                         20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35,
+                                         36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51};
+// deblocking tables (TLibCommon/TComLoopFilter.cpp:63-71)
+__constant__ uint8_t kTc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  1,  1,  1,  1,  1,  1,  1,  1,  1,
+                                2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9,  10, 11, 13, 14, 16, 18, 20, 22, 24};
+__constant__ uint8_t kBeta[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  6,  7,
+                                  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 20, 22, 24, 26, 28, 30, 32,
+                                  34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+
+// ------------------------------------------------------------------------------------------------
+// k_inter: motion-compensated prediction
+// ------------------------------------------------------------------------------------------------
+// Interpolation taps (TLibCommon/TComInterpolationFilter.cpp:55-73), packed one signed byte per tap so a
+// lane can pick its row with selects instead of a divergent table read.
+__device__ __forceinline__ void luma_taps(int frac, int c[8]) {
+  // {0,0,0,64,0,0,0,0} {-1,4,-10,58,17,-5,1,0} {-1,4,-11,40,40,-11,4,-1} {0,1,-5,17,58,-10,4,-1}
+  const int t1[8] = {-1, 4, -10, 58, 17, -5, 1, 0};
+  const int t2[8] = {-1, 4, -11, 40, 40, -11, 4, -1};
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    int id = (k == 3) ? 64 : 0;
+    c[k] = frac == 0 ? id : frac == 1 ? t1[k] : frac == 2 ? t2[k] : t1[7 - k];
+  }
+}
+__device__ __forceinline__ void chroma_taps(int frac, int c[4]) {
+  // rows 0..4 of the table; rows 5..7 are rows 3..1 mirrored
+  const int t[5][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}};
+  int f = frac <= 4 ? frac : 8 - frac;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int kk = frac <= 4 ? k : 3 - k;
+    int v = t[0][0];
+    v = f == 0 ? (kk == 0 ? t[0][0] : kk == 1 ? t[0][1] : kk == 2 ? t[0][2] : t[0][3]) : v;
+    v = f == 1 ? (kk == 0 ? t[1][0] : kk == 1 ? t[1][1] : kk == 2 ? t[1][2] : t[1][3]) : v;
+    v = f == 2 ? (kk == 0 ? t[2][0] : kk == 1 ? t[2][1] : kk == 2 ? t[2][2] : t[2][3]) : v;
+    v = f == 3 ? (kk == 0 ? t[3][0] : kk == 1 ? t[3][1] : kk == 2 ? t[3][2] : t[3][3]) : v;
+    v = f == 4 ? (kk == 0 ? t[4][0] : kk == 1 ? t[4][1] : kk == 2 ? t[4][2] : t[4][3]) : v;
+    c[k] = v;
+  }
+}
+
+// Separable interpolation of a BW x BH block with NT taps, producing the 14-bit intermediate of the
+// reference's bi-prediction path: horizontal pass (sum - (8192 << s1)) >> s1, s1 = bd - 8, then the
+// vertical pass sum >> 6 (TLibCommon/TComInterpolationFilter.cpp:165-246 with isLast = false).
+// Running a zero fraction through the identity filter {..64..} reproduces the reference's shortcut
+// paths exactly (filterCopy and the single-pass cases), and the uni-prediction result follows from
+// the same intermediate: clip((v + 8192 + (1 << (13 - bd))) >> (14 - bd)).
+// Reference samples outside the picture are read with clamped coordinates, which equals the
+// reference's replicated 80-sample border because clipped vectors never reach beyond it.
+template <typename pel_t, int NT, int BW, int BH>
+__device__ __forceinline__ void interp_block(const pel_t *ref, int stride, int pw, int ph, int x0, int y0, const int *cx,
+                                             const int *cy, int bd, int out[BH][BW]) {
+  const int s1 = bd - 8;
+  const int off1 = 8192 << s1;
+  int xo[BW + NT - 1];
+#pragma unroll
+  for (int i = 0; i < BW + NT - 1; i++) xo[i] = clip3i(0, pw - 1, x0 + i - (NT / 2 - 1));
+  int acc[BH][BW];
+#pragma unroll
+  for (int j = 0; j < BH; j++)
+#pragma unroll
+    for (int i = 0; i < BW; i++) acc[j][i] = 0;
+#pragma unroll
+  for (int r = 0; r < BH + NT - 1; r++) {
+    const pel_t *row = ref + (size_t)clip3i(0, ph - 1, y0 + r - (NT / 2 - 1)) * stride;
+    int px[BW + NT - 1];
+#pragma unroll
+    for (int i = 0; i < BW + NT - 1; i++) px[i] = row[xo[i]];
+#pragma unroll
+    for (int i = 0; i < BW; i++) {
+      int sum = 0;
+#pragma unroll
+      for (int k = 0; k < NT; k++) sum += cx[k] * px[i + k];
+      int h = (sum - off1) >> s1;  // 16-bit intermediate of the reference
+#pragma unroll
+      for (int j = 0; j < BH; j++) {
+        const int k = r - j;  // tap index of this row for output row j
+        if (k >= 0 && k < NT) acc[j][i] += cy[k] * h;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BH; j++)
+#pragma unroll
+    for (int i = 0; i < BW; i++) out[j][i] = acc[j][i] >> 6;
+}
+
+template <typename pel_t>
+__global__ __launch_bounds__(256) void k_inter(const PicJob *jobs, SeqInfo s) {
+  const PicJob &J = jobs[blockIdx.y];
+  const int cx = blockIdx.x % s.ctus_w, cy = blockIdx.x / s.ctus_w;
+  const int ux = cx * 16 + (threadIdx.x & 15), uy = cy * 16 + (threadIdx.x >> 4);
+  if (J.slice_type == 2 || ux >= s.uw || uy >= s.uh) return;
+  const Part4 p = J.rec4[(size_t)uy * s.uw + ux];
+  if (p.flags & P4_INTRA) return;
+  const int x = ux * 4, y = uy * 4;
+  // TComDataCU::clipMv (TLibCommon/TComDataCU.cpp:3207-3219): the range depends on the coding unit's origin.
+  const int cusize = 64 >> (p.flags & P4_DEPTH_MASK);
+  const int cux = x & ~(cusize - 1), cuy = y & ~(cusize - 1);
+  const int hmax = (s.w + 8 - cux - 1) << 2, hmin = (-64 - 8 - cux + 1) << 2;
+  const int vmax = (s.h + 8 - cuy - 1) << 2, vmin = (-64 - 8 - cuy + 1) << 2;
+  bool use0 = p.ref_idx[0] >= 0, use1 = p.ref_idx[1] >= 0;
+  // TComPrediction::xCheckIdenticalMotion (TLibCommon/TComPrediction.cpp:396-411)
+  if (use0 && use1 && J.slice_type == 0 && J.ref_poc[0][p.ref_idx[0]] == J.ref_poc[1][p.ref_idx[1]] && p.mv[0][0] == p.mv[1][0] &&
+      p.mv[0][1] == p.mv[1][1])
+    use1 = false;
+  const bool bi = use0 && use1;
+  int ly[4][4], lc[2][2][2];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) ly[j][i] = 0;
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int i = 0; i < 2; i++) lc[c][j][i] = 0;
+  for (int l = 0; l < 2; l++) {
+    if (!(l ? use1 : use0)) continue;
+    const int ri = p.ref_idx[l];
+    const int mvx = min(hmax, max(hmin, (int)p.mv[l][0])), mvy = min(vmax, max(vmin, (int)p.mv[l][1]));
+    {
+      int tx[8], ty[8], o[4][4];
+      luma_taps(mvx & 3, tx);
+      luma_taps(mvy & 3, ty);
+      interp_block<pel_t, 8, 4, 4>(plane_c<pel_t>(J.ref[l][ri][0]), s.stride_y, s.w, s.h, x + (mvx >> 2), y + (mvy >> 2), tx, ty,
+                                   s.bd_y, o);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) ly[j][i] += o[j][i];
+    }
+    {
+      int tx[4], ty[4];
+      chroma_taps(mvx & 7, tx);
+      chroma_taps(mvy & 7, ty);
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        int o[2][2];
+        interp_block<pel_t, 4, 2, 2>(plane_c<pel_t>(J.ref[l][ri][1 + c]), s.stride_c, s.cw, s.ch, (x >> 1) + (mvx >> 3),
+                                     (y >> 1) + (mvy >> 3), tx, ty, s.bd_c, o);
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int i = 0; i < 2; i++) lc[c][j][i] += o[j][i];
+      }
+    }
+  }
+  // uni: clip((v + 8192 + rnd) >> (14 - bd)); bi: TComYuv::addAvg (TLibCommon/TComYuv.cpp:520-584)
+  {
+    const int head = 14 - s.bd_y, maxv = (1 << s.bd_y) - 1;
+    const int sh = bi ? head + 1 : head, off = bi ? 16384 + (1 << head) : 8192 + (head ? (1 << (head - 1)) : 0);
+    pel_t *dst = (pel_t *)J.rec[0] + (size_t)y * s.stride_y + x;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[i] = (pel_t)clip3i(0, maxv, (ly[j][i] + off) >> sh);
+      dst += s.stride_y;
+    }
+  }
+  {
+    const int head = 14 - s.bd_c, maxv = (1 << s.bd_c) - 1;
+    const int sh = bi ? head + 1 : head, off = bi ? 16384 + (1 << head) : 8192 + (head ? (1 << (head - 1)) : 0);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      pel_t *dst = (pel_t *)J.rec[1 + c] + (size_t)(y >> 1) * s.stride_c + (x >> 1);
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) dst[i] = (pel_t)clip3i(0, maxv, (lc[c][j][i] + off) >> sh);
+        dst += s.stride_c;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_transform: de-quantisation + inverse transform
+// ------------------------------------------------------------------------------------------------
+// N lanes per transform block, 256/N blocks per workgroup.  Pass 1: lane c owns column c of the
+// coefficients and produces column c of the intermediate (N sums over the rows); pass 2: lane y owns
+// row y of the intermediate and produces row y of the residual.  This is the plain matrix form of the
+// reference's partial butterflies (TLibCommon/TComTrQuant.cpp:464-863: same sums, shifts 7 and
+// 12-(bd-8), 16-bit clip after each pass); the matrix entry is wave-uniform in both passes, and a
+// coefficient row that is zero in the whole wave is skipped.
+// De-quantisation: TComTrQuant::xDeQuant flat path (TLibCommon/TComTrQuant.cpp:1174-1185) with the QP of
+// TComTrQuant::setQPforQuant (:192-214); transform skip: xITransformSkip (:1454-1486).
+template <typename pel_t, int LOG2N>
+__global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s) {
+  constexpr int N = 1 << LOG2N;
+  constexpr int TPB = 256 / N;  // transform blocks per workgroup
+  __shared__ int tmp[TPB][N][N + 1];
+  const PicJob &J = jobs[blockIdx.y];
+  const int t_local = threadIdx.x / N, c = threadIdx.x % N;
+  const int t_idx = blockIdx.x * TPB + t_local;
+  const bool live = t_idx < J.n_tu[LOG2N - 2];
+  TuItem it;
+  it.x = it.y = 0;
+  it.comp = it.flags = 0;
+  it.qp = 0;
+  it.coeff_off = 0;
+  if (live) it = J.tu[LOG2N - 2][t_idx];
+  const int comp = it.comp;
+  const int bd = comp ? s.bd_c : s.bd_y;
+  // QP
+  int q;
+  if (comp == 0) {
+    q = it.qp + 6 * (s.bd_y - 8);
+  } else {
+    const int bdo = 6 * (s.bd_c - 8);
+    int qc = clip3i(-bdo, 57, it.qp + (comp == 1 ? J.cb_off : J.cr_off));
+    q = qc < 0 ? qc + bdo : kChromaScale[qc] + bdo;
+  }
+  const int per = q / 6, rem = q - per * 6;
+  const int iq = rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72;
+  const int scale = iq << per;
+  const int shift = bd + LOG2N - 9, add = 1 << (shift - 1);
+  const int16_t *coef = J.coeff + it.coeff_off;
+  const bool tskip = (it.flags & TU_TSKIP) != 0;
+  const bool dst4 = LOG2N == 2 && (it.flags & TU_DST);
+
+  // ---- pass 1 (columns) ----
+  int acc[N];
+#pragma unroll
+  for (int y = 0; y < N; y++) acc[y] = 0;
+  for (int k = 0; k < N; k++) {
+    int d = 0;
+    if (live) {
+      int v = coef[k * N + c];
+      d = clip3i(-32768, 32767, (v * scale + add) >> shift);
+    }
+    if (tskip) tmp[t_local][k][c] = d;  // transform-skip blocks bypass both passes: keep the de-quantised block as it is
+    const int dd = tskip ? 0 : d;
+    if (!__any(dd != 0)) continue;  // wave-uniform
+#pragma unroll
+    for (int y = 0; y < N; y++) {
+      const int m = kT32[k * (32 / N)][y];
+      const int md = (LOG2N == 2) ? kDst4[k][y & 3] : 0;
+      acc[y] += (dst4 ? md : m) * dd;
+    }
+  }
+  if (!tskip) {
+#pragma unroll
+    for (int y = 0; y < N; y++) tmp[t_local][y][c] = clip3i(-32768, 32767, (acc[y] + 64) >> 7);
+  }
+  __syncthreads();
+  // ---- pass 2 (rows): lane c now owns row y = c ----
+  const int y = c;
+  int res[N];
+#pragma unroll
+  for (int x = 0; x < N; x++) res[x] = 0;
+  for (int k = 0; k < N; k++) {
+    const int v = tskip ? 0 : tmp[t_local][y][k];
+    if (!__any(v != 0)) continue;  // wave-uniform
+#pragma unroll
+    for (int x = 0; x < N; x++) {
+      const int m = kT32[k * (32 / N)][x];
+      const int md = (LOG2N == 2) ? kDst4[k][x & 3] : 0;
+      res[x] += (dst4 ? md : m) * v;
+    }
+  }
+  if (tskip) {
+    const int ts = 15 - bd - LOG2N;  // > 0 for every supported bit depth
+#pragma unroll
+    for (int x = 0; x < N; x++) res[x] = (tmp[t_local][y][x] + (1 << (ts - 1))) >> ts;
+  } else {
+    const int s2 = 12 - (bd - 8), r2 = 1 << (s2 - 1);
+#pragma unroll
+    for (int x = 0; x < N; x++) res[x] = clip3i(-32768, 32767, (res[x] + r2) >> s2);
+  }
+  if (!live) return;
+  if (it.flags & TU_TO_RESI) {
+    int16_t *o = J.resi + it.coeff_off + y * N;
+#pragma unroll
+    for (int x = 0; x < N; x++) o[x] = (int16_t)res[x];
+  } else {
+    // TDecCu::xReconInter / TComYuv::addClip (TLibDecoder/TDecCu.cpp:468-486, TLibCommon/TComYuv.cpp:401-459):
+    // adding a zero residual is the identity, so only coded blocks need touching.
+    const int stride = comp ? s.stride_c : s.stride_y, maxv = (1 << bd) - 1;
+    pel_t *o = (pel_t *)J.rec[comp] + (size_t)(it.y + y) * stride + it.x;
+#pragma unroll
+    for (int x = 0; x < N; x++) o[x] = (pel_t)clip3i(0, maxv, (int)o[x] + res[x]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_intra: intra prediction + residual add, one wave per block, one launch per dependency level
+// ------------------------------------------------------------------------------------------------
+// Reference-sample array r[0..4n]: r[2n] is the corner, r[2n-1-j] the left column going down,
+// r[2n+1+i] the row above going right (TComPattern::initAdiPattern / fillReferenceSamples,
+// TLibCommon/TComPattern.cpp:213-602).  Availability comes per 4-luma-sample unit from the packer.
+template <typename pel_t>
+__global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, int level) {
+  __shared__ int raw_s[4][132], ref_s[4][132], flt_s[4][132];
+  const PicJob &J = jobs[blockIdx.y];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int first = 0, count = 0;
+  if (level < J.n_levels) {
+    first = J.level_off[level];
+    count = J.level_off[level + 1] - first;
+  }
+  const int idx = blockIdx.x * 4 + wv;
+  const bool live = idx < count;
+  IntraItem it;
+  it.x = it.y = 0;
+  it.log2n = 2;
+  it.comp = 0;
+  it.mode = 1;
+  it.flags = 0;
+  it.avail_left = it.avail_above = 0;
+  it.resi_off = 0;
+  if (live) it = J.intra[first + idx];
+  const int n = 1 << it.log2n, comp = it.comp;
+  const int sh = comp ? 1 : 0, us = 4 >> sh, nu = n / us;
+  const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
+  const int stride = comp ? s.stride_c : s.stride_y;
+  pel_t *plane = (pel_t *)J.rec[comp];
+  int *raw = raw_s[wv], *ref = ref_s[wv], *flt = flt_s[wv];
+  const int x0 = it.x, y0 = it.y, len = 4 * n + 1;
+
+  // availability of the 4*nu+1 units in scan order (bottom-left ... corner ... top-right)
+  unsigned long long m = 0;
+  for (int j = 0; j < 2 * nu; j++)
+    if ((it.avail_left >> j) & 1) m |= 1ull << (2 * nu - 1 - j);
+  if (it.flags & IN_CORNER) m |= 1ull << (2 * nu);
+  for (int i = 0; i < 2 * nu; i++)
+    if ((it.avail_above >> i) & 1) m |= 1ull << (2 * nu + 1 + i);
+
+  // 1. gather
+  for (int i = lane; i < len; i += 64) {
+    int u, sx, sy;
+    if (i < 2 * n) {
+      u = i / us;
+      sx = x0 - 1;
+      sy = y0 + 2 * n - 1 - i;
+    } else if (i == 2 * n) {
+      u = 2 * nu;
+      sx = x0 - 1;
+      sy = y0 - 1;
+    } else {
+      u = 2 * nu + 1 + (i - 2 * n - 1) / us;
+      sx = x0 + (i - 2 * n - 1);
+      sy = y0 - 1;
+    }
+    int v = 0;
+    if (live && ((m >> u) & 1)) v = plane[(size_t)sy * stride + sx];
+    raw[i] = v;
+  }
+  __syncthreads();
+  // 2. substitution of unavailable units (TLibCommon/TComPattern.cpp:424-435,546-588)
+  for (int i = lane; i < len; i += 64) {
+    const int u = i < 2 * n ? i / us : (i == 2 * n ? 2 * nu : 2 * nu + 1 + (i - 2 * n - 1) / us);
+    int v;
+    if ((m >> u) & 1) {
+      v = raw[i];
+    } else if (m == 0) {
+      v = 1 << (bd - 1);
+    } else {
+      const unsigned long long below = m & ((1ull << u) - 1);
+      int src;
+      if (below) {
+        const int ub = 63 - __clzll((long long)below);  // nearest available unit before this one: take its last sample
+        src = ub < 2 * nu ? ub * us + us - 1 : (ub == 2 * nu ? 2 * n : 2 * n + 1 + (ub - 2 * nu - 1) * us + us - 1);
+      } else {
+        const int ua = __ffsll((long long)m) - 1;  // none before: first sample of the first available unit
+        src = ua < 2 * nu ? ua * us : (ua == 2 * nu ? 2 * n : 2 * n + 1 + (ua - 2 * nu - 1) * us);
+      }
+      v = raw[src];
+    }
+    ref[i] = v;
+  }
+  __syncthreads();
+  // 3. luma smoothing (TComPattern::getPredictorPtr :627-651 decides, :263-356 filters)
+  const int mode = it.mode;
+  bool use_flt = false;
+  if (comp == 0 && mode != 1) {
+    const int thr = it.log2n == 2 ? 10 : it.log2n == 3 ? 7 : it.log2n == 4 ? 1 : 0;
+    use_flt = min(iabs(mode - 10), iabs(mode - 26)) > thr;
+  }
+  if (use_flt) {
+    bool strong = false;
+    if (s.strong_intra && n >= 32) {
+      const int thr = 1 << (bd - 5);
+      strong = iabs(ref[0] + ref[2 * n] - 2 * ref[n]) < thr && iabs(ref[2 * n] + ref[4 * n] - 2 * ref[3 * n]) < thr;
+    }
+    for (int i = lane; i < len; i += 64) {
+      int v;
+      if (i == 0 || i == len - 1) {
+        v = ref[i];
+      } else if (strong) {
+        // bilinear between the three corners; n = 32 so the shift is log2(2n) = 6
+        if (i < 2 * n)
+          v = ((2 * n - i) * ref[0] + i * ref[2 * n] + n) >> 6;
+        else if (i == 2 * n)
+          v = ref[i];
+        else
+          v = ((2 * n - (i - 2 * n)) * ref[2 * n] + (i - 2 * n) * ref[4 * n] + n) >> 6;
+      } else {
+        v = (ref[i - 1] + 2 * ref[i] + ref[i + 1] + 2) >> 2;
+      }
+      flt[i] = v;
+    }
+  }
+  __syncthreads();
+  const int *r = use_flt ? flt : ref;
+  const int *cn = r + 2 * n;  // cn[0] corner, cn[-1-j] left[j], cn[1+i] above[i]
+  // DC value: wave reduction over the 2n neighbours (TLibCommon/TComPrediction.cpp:122-160)
+  int dcv = 0;
+  {
+    int part = 0;
+    if (lane < 2 * n) part = lane < n ? cn[1 + lane] : cn[-1 - (lane - n)];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+    dcv = (part + n) >> (it.log2n + 1);
+  }
+  // 4. prediction (TLibCommon/TComPrediction.cpp:183-390,691-763) + residual + store
+  const bool edge = comp == 0 && n <= 16;
+  const bool hor = mode >= 2 && mode < 18;
+  int angle = 0, inv = 0;
+  if (mode >= 2) {
+    const int a = hor ? -(mode - 10) : mode - 26;
+    const int aa = iabs(a);
+    const int at = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
+    inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
+    angle = a < 0 ? -at : at;
+  }
+  const int16_t *resi = J.resi + it.resi_off;
+  const bool has_resi = (it.flags & IN_HAS_RESI) != 0;
+  for (int p = lane; p < n * n; p += 64) {
+    const int py = p >> it.log2n, px = p & (n - 1);
+    int v;
+    if (mode == 0) {  // planar
+      const int l = cn[-1 - py], a = cn[1 + px];
+      const int hp = (l << it.log2n) + n + (px + 1) * (cn[1 + n] - l);
+      const int vp = (a << it.log2n) + (py + 1) * (cn[-1 - n] - a);
+      v = (hp + vp) >> (it.log2n + 1);
+    } else if (mode == 1) {  // DC
+      v = dcv;
+      if (edge) {
+        if (px == 0 && py == 0)
+          v = (cn[1] + cn[-1] + 2 * dcv + 2) >> 2;
+        else if (py == 0)
+          v = (cn[1 + px] + 3 * dcv + 2) >> 2;
+        else if (px == 0)
+          v = (cn[-1 - py] + 3 * dcv + 2) >> 2;
+      }
+    } else {
+      // angular: vertical modes predict from the row above, horizontal modes are the same computation
+      // on the transposed block (main = left column)
+      const int k = hor ? px : py;  // index along the prediction direction
+      const int e = hor ? py : px;  // index across it
+#define MAIN(i) (hor ? cn[-(i)] : cn[(i)])
+#define SIDE(i) (hor ? cn[(i)] : cn[-(i)])
+      if (angle == 0) {
+        v = MAIN(e + 1);
+        if (edge && e == 0) v = clip3i(0, maxv, v + ((SIDE(k + 1) - SIDE(0)) >> 1));
+      } else {
+        const int pos = (k + 1) * angle;
+        const int di = pos >> 5, df = pos & 31;
+        const int i0 = e + di + 1, i1 = i0 + 1;
+        // negative indices address the side reference projected onto the main one
+        const int a0 = i0 >= 0 ? MAIN(i0) : SIDE((128 - i0 * inv) >> 8);
+        const int a1 = i1 >= 0 ? MAIN(i1) : SIDE((128 - i1 * inv) >> 8);
+        v = df ? ((32 - df) * a0 + df * a1 + 16) >> 5 : a0;
+      }
+#undef MAIN
+#undef SIDE
+    }
+    if (live) {
+      if (has_resi) v += resi[p];
+      plane[(size_t)(y0 + py) * stride + x0 + px] = (pel_t)clip3i(0, maxv, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_deblock: one lane per 4-sample edge segment
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int tu_size_of(const Part4 &p) { return (64 >> (p.flags & P4_DEPTH_MASK)) >> (p.tu & P4_TRIDX_MASK); }
+
+// TComLoopFilter::xGetBoundaryStrengthSingle (TLibCommon/TComLoopFilter.cpp:421-543)
+__device__ __forceinline__ int boundary_strength(const PicJob &J, const Part4 &P, const Part4 &Q, bool tu_edge) {
+  if ((P.flags | Q.flags) & P4_INTRA) return 2;
+  if (tu_edge && ((P.tu | Q.tu) & P4_CBF_Y)) return 1;
+  const int none = -0x7fffffff;
+  const int rp0 = P.ref_idx[0] < 0 ? none : J.ref_poc[0][P.ref_idx[0]];
+  const int rq0 = Q.ref_idx[0] < 0 ? none : J.ref_poc[0][Q.ref_idx[0]];
+#define FAR(a, b) (iabs((a)[0] - (b)[0]) >= 4 || iabs((a)[1] - (b)[1]) >= 4)
+  if (J.slice_type == 0) {
+    const int rp1 = P.ref_idx[1] < 0 ? none : J.ref_poc[1][P.ref_idx[1]];
+    const int rq1 = Q.ref_idx[1] < 0 ? none : J.ref_poc[1][Q.ref_idx[1]];
+    if ((rp0 == rq0 && rp1 == rq1) || (rp0 == rq1 && rp1 == rq0)) {
+      if (rp0 != rp1) {
+        if (rp0 == rq0) return FAR(P.mv[0], Q.mv[0]) || FAR(P.mv[1], Q.mv[1]);
+        return FAR(P.mv[0], Q.mv[1]) || FAR(P.mv[1], Q.mv[0]);
+      }
+      return (FAR(P.mv[0], Q.mv[1]) || FAR(P.mv[1], Q.mv[0])) && (FAR(P.mv[0], Q.mv[0]) || FAR(P.mv[1], Q.mv[1]));
+    }
+    return 1;
+  }
+  return rp0 != rq0 || FAR(P.mv[0], Q.mv[0]);
+#undef FAR
+}
+
+// DIR 0: vertical edges (filtering across x), DIR 1: horizontal edges.  Edges lie on the 8-sample
+// grid and change at most 3 samples on either side while reading 4, so all segments of one direction
+// are independent and the pass runs in place (TComLoopFilter::loopFilterPic, TLibCommon/TComLoopFilter.cpp:142-174,
+// does all vertical edges of the picture before any horizontal one; so do the two launches).
+// Edge selection: xSetEdgefilterTU / xSetEdgefilterPU / xSetLoopfilterParam (:276-419) for one slice, one tile.
+// Luma filter: xEdgeFilterLuma / xPelFilterLuma (:546-660,809-868); chroma: xEdgeFilterChroma / xPelFilterChroma (:663-792,879-900).
+template <typename pel_t, int DIR>
+__global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) {
+  const PicJob &J = jobs[blockIdx.y];
+  if (J.deblock_disable) return;
+  // segment grid: along the edge in 4-sample units, across in 8-sample steps
+  const int n_edge = DIR == 0 ? s.w / 8 : s.h / 8;  // edge positions (position 0 = picture border, skipped)
+  const int n_unit = DIR == 0 ? s.uh : s.uw;
+  const int fast_n = DIR == 0 ? n_edge : n_unit;     // fastest-varying index runs along x in both cases
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int fi = gid % fast_n, si = gid / fast_n;
+  const int e = DIR == 0 ? fi : si, u = DIR == 0 ? si : fi;
+  if (e == 0 || e >= n_edge || u >= n_unit) return;
+  const int x = DIR == 0 ? e * 8 : u * 4, y = DIR == 0 ? u * 4 : e * 8;
+  const int ux = x >> 2, uy = y >> 2;
+  const Part4 Q = J.rec4[(size_t)uy * s.uw + ux];
+  const Part4 P = DIR == 0 ? J.rec4[(size_t)uy * s.uw + ux - 1] : J.rec4[(size_t)(uy - 1) * s.uw + ux];
+  const int pos = DIR == 0 ? x : y;
+  const bool tu_edge = (pos & (tu_size_of(Q) - 1)) == 0;
+  if (!tu_edge) {
+    // prediction-block edge inside the coding unit?
+    const int cus = 64 >> (Q.flags & P4_DEPTH_MASK);
+    const int rel = pos & (cus - 1);
+    const int ps = (Q.flags >> P4_PARTSIZE_SHIFT) & 7;
+    int pe = -1;
+    if (DIR == 0) {
+      if (ps == 2 || ps == 3) pe = cus >> 1;
+      if (ps == 6) pe = cus >> 2;
+      if (ps == 7) pe = cus - (cus >> 2);
+    } else {
+      if (ps == 1 || ps == 3) pe = cus >> 1;
+      if (ps == 4) pe = cus >> 2;
+      if (ps == 5) pe = cus - (cus >> 2);
+    }
+    if (rel != pe) return;
+  }
+  const int bs = boundary_strength(J, P, Q, tu_edge);
+  if (!bs) return;
+  const int qp = (P.qp + Q.qp + 1) >> 1;
+  {
+    const int scale = 1 << (s.bd_y - 8), maxv = (1 << s.bd_y) - 1;
+    const int tc = kTc[clip3i(0, 53, qp + 2 * (bs - 1) + 2 * J.tc_off_div2)] * scale;
+    const int beta = kBeta[clip3i(0, 51, qp + 2 * J.beta_off_div2)] * scale;
+    const int step = DIR == 0 ? 1 : s.stride_y, line = DIR == 0 ? s.stride_y : 1;
+    pel_t *sp = (pel_t *)J.rec[0] + (size_t)y * s.stride_y + x;
+    int m[4][8];  // m[k][0..3] = p3..p0, m[k][4..7] = q0..q3 of line k
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int i = 0; i < 8; i++) m[k][i] = sp[k * line + (i - 4) * step];
+    const int dp0 = iabs(m[0][1] - 2 * m[0][2] + m[0][3]), dq0 = iabs(m[0][4] - 2 * m[0][5] + m[0][6]);
+    const int dp3 = iabs(m[3][1] - 2 * m[3][2] + m[3][3]), dq3 = iabs(m[3][4] - 2 * m[3][5] + m[3][6]);
+    const int d0 = dp0 + dq0, d3 = dp3 + dq3, d = d0 + d3;
+    if (d < beta) {
+      const int side = (beta + (beta >> 1)) >> 3;
+      const bool fp = dp0 + dp3 < side, fq = dq0 + dq3 < side;
+      const bool sw0 = iabs(m[0][0] - m[0][3]) + iabs(m[0][7] - m[0][4]) < (beta >> 3) && 2 * d0 < (beta >> 2) &&
+                       iabs(m[0][3] - m[0][4]) < ((tc * 5 + 1) >> 1);
+      const bool sw3 = iabs(m[3][0] - m[3][3]) + iabs(m[3][7] - m[3][4]) < (beta >> 3) && 2 * d3 < (beta >> 2) &&
+                       iabs(m[3][3] - m[3][4]) < ((tc * 5 + 1) >> 1);
+      const bool sw = sw0 && sw3;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int m0 = m[k][0], m1 = m[k][1], m2 = m[k][2], m3 = m[k][3], m4 = m[k][4], m5 = m[k][5], m6 = m[k][6], m7 = m[k][7];
+        pel_t *o = sp + k * line;
+        if (sw) {
+          o[-step] = (pel_t)clip3i(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
+          o[0] = (pel_t)clip3i(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
+          o[-2 * step] = (pel_t)clip3i(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
+          o[step] = (pel_t)clip3i(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
+          o[-3 * step] = (pel_t)clip3i(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
+          o[2 * step] = (pel_t)clip3i(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
+        } else {
+          int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+          if (iabs(delta) < tc * 10) {
+            delta = clip3i(-tc, tc, delta);
+            o[-step] = (pel_t)clip3i(0, maxv, m3 + delta);
+            o[0] = (pel_t)clip3i(0, maxv, m4 - delta);
+            const int tc2 = tc >> 1;
+            if (fp) o[-2 * step] = (pel_t)clip3i(0, maxv, m2 + clip3i(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)));
+            if (fq) o[step] = (pel_t)clip3i(0, maxv, m5 + clip3i(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
+          }
+        }
+      }
+    }
+  }
+  // chroma: only strength 2, only edges on the 8-chroma-sample grid; this unit owns 2 chroma lines
+  if (bs == 2 && (pos & 15) == 0) {
+    const int scale = 1 << (s.bd_c - 8), maxv = (1 << s.bd_c) - 1;
+    const int step = DIR == 0 ? 1 : s.stride_c, line = DIR == 0 ? s.stride_c : 1;
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      int qc = qp + (c == 0 ? J.cb_off_pps : J.cr_off_pps);
+      qc = qc < 0 ? qc : (qc > 57 ? qc - 6 : kChromaScale[qc]);
+      const int tc = kTc[clip3i(0, 53, qc + 2 + 2 * J.tc_off_div2)] * scale;
+      pel_t *sp = (pel_t *)J.rec[1 + c] + (size_t)(y >> 1) * s.stride_c + (x >> 1);
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        pel_t *o = sp + k * line;
+        const int m2 = o[-2 * step], m3 = o[-step], m4 = o[0], m5 = o[step];
+        const int delta = clip3i(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
+        o[-step] = (pel_t)clip3i(0, maxv, m3 + delta);
+        o[0] = (pel_t)clip3i(0, maxv, m4 - delta);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sao: sample adaptive offset, deblocked picture -> final picture
+// ------------------------------------------------------------------------------------------------
+// TComSampleAdaptiveOffset::processSaoUnitAll / processSaoCuOrg (TLibCommon/TComSampleAdaptiveOffset.cpp:814-1039,
+// 1097-1261).  The reference filters in place and saves the row above / column left of each CTU so that
+// classification always sees deblocked samples; reading a separate source picture is the same thing.
+// blockIdx.z = component.  One lane handles 4 consecutive samples of a row.
+template <typename pel_t>
+__global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
+  const PicJob &J = jobs[blockIdx.y];
+  const int comp = blockIdx.z;
+  const int pw = comp ? s.cw : s.w, ph = comp ? s.ch : s.h, stride = comp ? s.stride_c : s.stride_y;
+  const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
+  const int qw = pw >> 2;
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int qx = gid % qw, y = gid / qw;
+  if (y >= ph) return;
+  const int x = qx * 4;
+  const pel_t *src = (const pel_t *)J.rec[comp];
+  pel_t *dst = (pel_t *)J.out[comp];
+  const int csh = comp ? 5 : 6;
+  const SaoCtu sp = J.sao[((size_t)(y >> csh) * s.ctus_w + (x >> csh)) * 3 + comp];
+  const bool on = (comp ? J.sao_chroma : J.sao_luma) && sp.type >= 0;
+  const int inc = bd > 10 ? bd - 10 : 0;
+  int v[4];
+  const pel_t *row = src + (size_t)y * stride;
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = row[x + i];
+  if (on) {
+    if (sp.type == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int k = ((v[i] >> (bd - 5)) - sp.band) & 31;
+        const int o = k == 0 ? sp.offset[0] : k == 1 ? sp.offset[1] : k == 2 ? sp.offset[2] : k == 3 ? sp.offset[3] : 0;
+        v[i] = clip3i(0, maxv, v[i] + (o << inc));
+      }
+    } else {
+      const int dx = sp.type == 1 ? 0 : (sp.type == 3 ? -1 : 1), dy = sp.type == 0 ? 0 : 1;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int ax = x + i - dx, ay = y - dy, bx = x + i + dx, by = y + dy;
+        if (ax < 0 || bx < 0 || ax >= pw || bx >= pw || ay < 0 || by >= ph) continue;  // picture border samples stay
+        const int a = src[(size_t)ay * stride + ax], b = src[(size_t)by * stride + bx];
+        const int e = (v[i] > a) - (v[i] < a) + (v[i] > b) - (v[i] < b);  // -2..2
+        const int o = e == -2 ? sp.offset[0] : e == -1 ? sp.offset[1] : e == 1 ? sp.offset[2] : e == 2 ? sp.offset[3] : 0;
+        v[i] = clip3i(0, maxv, v[i] + (o << inc));
+      }
+    }
+  }
+  pel_t *orow = dst + (size_t)y * stride + x;
+#pragma unroll
+  for (int i = 0; i < 4; i++) orow[i] = (pel_t)v[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+#define LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
+
+template <typename pel_t>
+static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t st, int arg, int arg2) {
+  switch (kind) {
+    case K_INTER:
+      LAUNCH(k_inter<pel_t>, dim3(s.ctus_w * s.ctus_h, n), dim3(256), st, jobs, s);
+      break;
+    case K_TRANSFORM: {
+      // arg = log2 size, arg2 = max number of blocks of that size over the batch
+      const int tpb = 256 >> arg;
+      const dim3 g((arg2 + tpb - 1) / tpb, n);
+      if (arg == 2) LAUNCH((k_transform<pel_t, 2>), g, dim3(256), st, jobs, s);
+      if (arg == 3) LAUNCH((k_transform<pel_t, 3>), g, dim3(256), st, jobs, s);
+      if (arg == 4) LAUNCH((k_transform<pel_t, 4>), g, dim3(256), st, jobs, s);
+      if (arg == 5) LAUNCH((k_transform<pel_t, 5>), g, dim3(256), st, jobs, s);
+      break;
+    }
+    case K_INTRA:
+      // arg = level, arg2 = max number of blocks in that level over the batch
+      LAUNCH(k_intra<pel_t>, dim3((arg2 + 3) / 4, n), dim3(256), st, jobs, s, arg);
+      break;
+    case K_DEBLOCK_V:
+      LAUNCH((k_deblock<pel_t, 0>), dim3(((s.w / 8) * s.uh + 255) / 256, n), dim3(256), st, jobs, s);
+      break;
+    case K_DEBLOCK_H:
+      LAUNCH((k_deblock<pel_t, 1>), dim3(((s.h / 8) * s.uw + 255) / 256, n), dim3(256), st, jobs, s);
+      break;
+    case K_SAO:
+      LAUNCH(k_sao<pel_t>, dim3(((s.w / 4) * s.h + 255) / 256, n, 3), dim3(256), st, jobs, s);
+      break;
+    default:
+      break;
+  }
+}
+
+void hr_launch(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t st, int arg, int arg2) {
+  if (s.bd_y <= 8 && s.bd_c <= 8)
+    launch_all_t<uint8_t>(kind, jobs, n, s, st, arg, arg2);
+  else
+    launch_all_t<uint16_t>(kind, jobs, n, s, st, arg, arg2);
+}

@@ -1,0 +1,297 @@
+// packer.cpp — see packer.h.
+//
+// The walk below mirrors what the reference does per CTU when it reconstructs
+// (TDecCu::xDecompressCU, TLibDecoder/TDecCu.cpp:404-466; TComTrQuant::invRecurTransformNxN,
+// TLibCommon/TComTrQuant.cpp:1292-1335; TDecCu::xIntraLumaRecQT / xIntraChromaRecQT,
+// TLibDecoder/TDecCu.cpp:686-743) but instead of computing samples it only records WHAT has to be
+// computed, so that the GPU can do all blocks of a kind at once.
+#include "packer.h"
+#include <algorithm>
+#include <cstring>
+
+namespace {
+
+// z-scan <-> raster inside a 64x64 CTU of 4x4 partitions (x is the low bit of each pair).
+struct ZScan {
+  uint8_t x[256], y[256], z[16][16];
+  ZScan() {
+    for (int i = 0; i < 256; i++) {
+      int xx = 0, yy = 0;
+      for (int b = 0; b < 4; b++) {
+        xx |= ((i >> (2 * b)) & 1) << b;
+        yy |= ((i >> (2 * b + 1)) & 1) << b;
+      }
+      x[i] = (uint8_t)xx;
+      y[i] = (uint8_t)yy;
+      z[yy][xx] = (uint8_t)i;
+    }
+  }
+};
+const ZScan kZ;
+
+inline int16_t sat16(int32_t v) { return (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+inline int ilog2(int v) {
+  int l = 0;
+  while ((1 << l) < v) l++;
+  return l;
+}
+
+}  // namespace
+
+void PackedPicture::begin(const SeqInfo &s) {
+  seq = s;
+  rec4.assign((size_t)s.uw * s.uh, Part4());
+  std::memset(rec4.data(), 0, rec4.size() * sizeof(Part4));
+  for (int i = 0; i < 4; i++) tu[i].clear();
+  coeff.clear();
+  intra.clear();
+  intra_level.clear();
+  level_off.clear();
+  sao.assign((size_t)s.ctus_w * s.ctus_h * 3, SaoCtu());
+  lvl_y.assign((size_t)s.uw * s.uh, 0);
+  lvl_c.assign((size_t)s.uw * s.uh, 0);
+  mc_ref_samples = 0;
+  next_ctu = 0;
+  finished = false;
+  error.clear();
+}
+
+// Position in coding order of the 4x4 unit (ux, uy): CTUs in raster order, z-order inside.
+int PackedPicture::coding_order(int ux, int uy) const {
+  return ((uy >> 4) * seq.ctus_w + (ux >> 4)) * 256 + kZ.z[uy & 15][ux & 15];
+}
+
+bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
+  if (finished || addr != next_ctu || addr >= seq.ctus_w * seq.ctus_h) {
+    error = "CTUs must be added once each, in raster order";
+    return false;
+  }
+  next_ctu++;
+  for (int c = 0; c < 3; c++) {
+    SaoCtu &s = sao[(size_t)addr * 3 + c];
+    s.type = (int8_t)ctu->sao_type[c];
+    s.band = (int8_t)ctu->sao_subtype[c];
+    for (int i = 0; i < 4; i++) s.offset[i] = (int8_t)ctu->sao_offset[c][i];
+  }
+  walk_cu(ctu, (addr % seq.ctus_w) * 64, (addr / seq.ctus_w) * 64, 0, 0);
+  return error.empty();
+}
+
+void PackedPicture::walk_cu(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy, int z, int depth) {
+  const int size = 64 >> depth;
+  const int x = ctux + 4 * kZ.x[z], y = ctuy + 4 * kZ.y[z];
+  const bool boundary = x + size > seq.w || y + size > seq.h;
+  if ((depth < ctu->depth[z] && depth < 3) || boundary) {
+    if (depth >= 3) {
+      error = "coding unit crosses the picture boundary";
+      return;
+    }
+    const int np = 256 >> (2 * (depth + 1));
+    for (int q = 0; q < 4; q++) {
+      const int zq = z + q * np;
+      if (ctux + 4 * kZ.x[zq] < seq.w && ctuy + 4 * kZ.y[zq] < seq.h) walk_cu(ctu, ctux, ctuy, zq, depth + 1);
+    }
+    return;
+  }
+  const int np = (size >> 2) * (size >> 2);
+  const bool intra = ctu->pred_mode[z] == 1;
+  for (int zz = z; zz < z + np; zz++) {
+    const int ux = (ctux >> 2) + kZ.x[zz], uy = (ctuy >> 2) + kZ.y[zz];
+    Part4 &p = rec4[(size_t)uy * seq.uw + ux];
+    p.flags = (uint8_t)((ctu->depth[zz] & P4_DEPTH_MASK) | (ctu->pred_mode[zz] == 1 ? P4_INTRA : 0) |
+                        ((ctu->part_size[zz] & 7) << P4_PARTSIZE_SHIFT) |
+                        ((ctu->transquant_bypass && ctu->transquant_bypass[zz]) ? P4_BYPASS : 0) |
+                        ((ctu->ipcm && ctu->ipcm[zz]) ? P4_IPCM : 0));
+    p.tu = (uint8_t)((ctu->tr_idx[zz] & P4_TRIDX_MASK) | (((ctu->cbf[0][zz] >> ctu->tr_idx[zz]) & 1) ? P4_CBF_Y : 0) | P4_VALID);
+    p.qp = ctu->qp[zz];
+    for (int l = 0; l < 2; l++) {
+      p.ref_idx[l] = ctu->ref_idx[l][zz];
+      p.mv[l][0] = ctu->mv[l][2 * zz];
+      p.mv[l][1] = ctu->mv[l][2 * zz + 1];
+    }
+    if (!intra) {
+      int nref = (p.ref_idx[0] >= 0) + (p.ref_idx[1] >= 0);
+      mc_ref_samples += 24 * nref;  // 16 luma + 2 x 4 chroma samples per reference read
+    }
+  }
+  if ((ctu->ipcm && ctu->ipcm[z]) || (ctu->transquant_bypass && ctu->transquant_bypass[z])) {
+    error = "IPCM / transquant-bypass coding units are not supported";
+    return;
+  }
+  if (intra) {
+    // TDecCu::xReconIntraQT, TLibDecoder/TDecCu.cpp:652-674: all luma blocks of the CU, then all chroma blocks.
+    const int parts = ctu->part_size[z] == 3 ? 4 : 1;
+    const int init = parts == 4 ? 1 : 0;
+    for (int chroma = 0; chroma < 2; chroma++)
+      for (int pu = 0; pu < parts; pu++) intra_tus(ctu, ctux, ctuy, z, z + (parts == 4 ? pu * (np / 4) : 0), size >> init, init, chroma);
+  } else {
+    for (int comp = 0; comp < 3; comp++) inter_tus(ctu, ctux, ctuy, z, comp, z, size, 0);
+  }
+}
+
+// Appends one coded transform block: its work item and its coefficients (saturated to 16 bits, which
+// loses nothing because de-quantisation clips its input to 16 bits first: TLibCommon/TComTrQuant.cpp:1181).
+void PackedPicture::emit_tu(const hevcrecon_ctu_syntax *ctu, int comp, int z, int zcu, int x, int y, int log2n, int flags,
+                            uint32_t *off_out) {
+  const int n = 1 << log2n, nn = n * n;
+  const int32_t *src = ctu->coeff[comp] + (comp ? 4 * z : 16 * z);
+  const size_t off = coeff.size();
+  coeff.resize(off + nn);
+  int16_t *dst = &coeff[off];
+  for (int i = 0; i < nn; i++) dst[i] = sat16(src[i]);
+  TuItem t;
+  std::memset(&t, 0, sizeof(t));
+  t.x = (uint16_t)x;
+  t.y = (uint16_t)y;
+  t.comp = (uint8_t)comp;
+  t.flags = (uint8_t)(flags | (ctu->transform_skip[comp][z] ? TU_TSKIP : 0));
+  t.qp = ctu->qp[zcu];
+  t.coeff_off = (uint32_t)off;
+  tu[log2n - 2].push_back(t);
+  if (off_out) *off_out = (uint32_t)off;
+}
+
+void PackedPicture::inter_tus(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy, int zcu, int comp, int z, int size, int trdepth) {
+  if (!((ctu->cbf[comp][z] >> trdepth) & 1)) return;
+  if (trdepth < ctu->tr_idx[z]) {
+    const int np = (size >> 2) * (size >> 2) / 4;
+    for (int q = 0; q < 4; q++) inter_tus(ctu, ctux, ctuy, zcu, comp, z + q * np, size >> 1, trdepth + 1);
+    return;
+  }
+  int log2n = ilog2(size);
+  int x = ctux + 4 * kZ.x[z], y = ctuy + 4 * kZ.y[z];
+  if (comp) {
+    if (log2n == 2) {
+      if (z & 3) return;  // one 4x4 chroma block per 8x8 luma area, carried by its first quadrant
+    } else {
+      log2n--;
+    }
+    x >>= 1;
+    y >>= 1;
+  }
+  emit_tu(ctu, comp, z, zcu, x, y, log2n, 0, NULL);
+}
+
+void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z, int zcu, int x, int y, int log2n, int mode) {
+  const int n = 1 << log2n;
+  const int sh = comp ? 1 : 0;
+  const int us = 4 >> sh;           // samples per availability unit in this plane
+  const int nu = n / us;            // units per block side
+  const int ux0 = (x << sh) >> 2, uy0 = (y << sh) >> 2;
+  std::vector<uint16_t> &lvl = comp ? lvl_c : lvl_y;
+  const int cur = coding_order(ux0, uy0);
+  // A neighbouring unit can be used iff it is inside the picture and precedes this block in coding order
+  // (TComPattern::is*Available over TComDataCU::getPU*, TLibCommon/TComPattern.cpp:653-830,
+  // TLibCommon/TComDataCU.cpp:1141-1589, for one slice / one tile / unconstrained intra prediction).
+  int level = 0;
+  uint16_t left = 0, above = 0;
+  int corner = 0;
+  for (int j = 0; j < 2 * nu; j++) {
+    const int ux = ux0 - 1, uy = uy0 + j;
+    if (ux >= 0 && uy < seq.uh && coding_order(ux, uy) < cur) {
+      left |= (uint16_t)(1u << j);
+      level = std::max<int>(level, lvl[(size_t)uy * seq.uw + ux]);
+    }
+  }
+  for (int i = 0; i < 2 * nu; i++) {
+    const int ux = ux0 + i, uy = uy0 - 1;
+    if (uy >= 0 && ux < seq.uw && coding_order(ux, uy) < cur) {
+      above |= (uint16_t)(1u << i);
+      level = std::max<int>(level, lvl[(size_t)uy * seq.uw + ux]);
+    }
+  }
+  if (ux0 > 0 && uy0 > 0) {
+    corner = 1;
+    level = std::max<int>(level, lvl[(size_t)(uy0 - 1) * seq.uw + ux0 - 1]);
+  }
+  level += 1;
+  if (comp < 2)  // Cb and Cr share one map; Cr arrives right after Cb with identical geometry
+    for (int j = 0; j < nu; j++)
+      for (int i = 0; i < nu; i++) lvl[(size_t)(uy0 + j) * seq.uw + ux0 + i] = (uint16_t)level;
+  IntraItem it;
+  std::memset(&it, 0, sizeof(it));
+  it.x = (uint16_t)x;
+  it.y = (uint16_t)y;
+  it.log2n = (uint8_t)log2n;
+  it.comp = (uint8_t)comp;
+  it.mode = (uint8_t)mode;
+  it.flags = (uint8_t)(corner ? IN_CORNER : 0);
+  it.avail_left = left;
+  it.avail_above = above;
+  it.resi_off = 0;
+  if ((ctu->cbf[comp][z] >> ctu->tr_idx[z]) & 1) {
+    uint32_t off = 0;
+    emit_tu(ctu, comp, z, zcu, x, y, log2n, TU_TO_RESI | ((comp == 0 && log2n == 2) ? TU_DST : 0), &off);
+    it.flags |= IN_HAS_RESI;
+    it.resi_off = off;
+  }
+  intra.push_back(it);
+  intra_level.push_back((uint16_t)level);
+}
+
+void PackedPicture::intra_tus(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy, int zcu, int z, int size, int trdepth, int chroma) {
+  if (trdepth < ctu->tr_idx[z]) {
+    const int np = (size >> 2) * (size >> 2) / 4;
+    for (int q = 0; q < 4; q++) intra_tus(ctu, ctux, ctuy, zcu, z + q * np, size >> 1, trdepth + 1, chroma);
+    return;
+  }
+  const int x = ctux + 4 * kZ.x[z], y = ctuy + 4 * kZ.y[z];
+  const int log2n = ilog2(size);
+  if (!chroma) {
+    emit_intra(ctu, 0, z, zcu, x, y, log2n, ctu->luma_dir[z]);
+    return;
+  }
+  int clog2 = log2n - 1;
+  if (log2n == 2) {
+    if (z & 3) return;
+    clog2 = 2;
+  }
+  int mode = ctu->chroma_dir[zcu];
+  if (mode == 36) mode = ctu->luma_dir[zcu];  // derived mode (TLibDecoder/TDecCu.cpp:608-611)
+  emit_intra(ctu, 1, z, zcu, x >> 1, y >> 1, clog2, mode);
+  emit_intra(ctu, 2, z, zcu, x >> 1, y >> 1, clog2, mode);
+}
+
+bool PackedPicture::finish(const hevcrecon_pic_params *p) {
+  if (next_ctu != seq.ctus_w * seq.ctus_h) {
+    error = "picture closed before all CTUs were added";
+    return false;
+  }
+  pp = *p;
+  for (int l = 0; l < 2; l++)
+    if (pp.num_ref[l] < 0 || pp.num_ref[l] > HR_MAX_REFS) {
+      error = "bad reference list size";
+      return false;
+    }
+  // counting sort of the intra blocks by dependency level
+  int nlev = 0;
+  for (size_t i = 0; i < intra_level.size(); i++) nlev = std::max<int>(nlev, intra_level[i]);
+  std::vector<int32_t> count(nlev + 1, 0);  // levels start at 1
+  for (size_t i = 0; i < intra_level.size(); i++) count[intra_level[i]]++;
+  level_off.assign(nlev + 1, 0);  // level_off[l-1] = first item of level l; level_off[nlev] = total
+  int run = 0;
+  for (int l = 1; l <= nlev; l++) {
+    level_off[l - 1] = run;
+    run += count[l];
+  }
+  level_off[nlev] = run;
+  std::vector<IntraItem> sorted(intra.size());
+  std::vector<int32_t> cursor(level_off.begin(), level_off.end());
+  for (size_t i = 0; i < intra.size(); i++) sorted[cursor[intra_level[i] - 1]++] = intra[i];
+  intra.swap(sorted);
+  finished = true;
+  return true;
+}
+
+int64_t PackedPicture::algorithmic_bytes() const {
+  const int64_t by = seq.bd_y > 8 ? 2 : 1, bc = seq.bd_c > 8 ? 2 : 1;
+  const int64_t sy = (int64_t)seq.w * seq.h, sc = (int64_t)seq.cw * seq.ch * 2;
+  const int64_t sample_bytes = sy * by + sc * bc;
+  const bool sao = pp.sao_luma || pp.sao_chroma;
+  // one store of the reconstruction, read+write by deblocking, read+write by SAO when it is on
+  int64_t total = sample_bytes * (1 + 2 + (sao ? 2 : 0));
+  total += mc_ref_samples * by;  // luma and chroma have the same sample size in every supported profile
+  total += 2 * (int64_t)coeff.size();
+  total += 16 * (int64_t)seq.uw * seq.uh;
+  return total;
+}

@@ -1,0 +1,141 @@
+"""Thin object wrapper over the engine's C ABI (include/hevcrecon.h), for tests and the benchmark.
+
+Method names follow the C entry points one for one.  All compute happens in
+libhevcrecon.so (HIP, gfx950); nothing here touches samples except to copy
+them in and out of numpy arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Syntax:
+    """One hevcrecon_syntax object: packs a PictureSyntax and keeps its copy in HBM."""
+
+    def __init__(self, engine, handle):
+        self.engine = engine
+        self.lib = engine.lib
+        self.h = handle
+        self.poc = None
+
+    def pack(self, pic):
+        """begin + add_ctu for every CTU + finish (which queues the upload)."""
+        lib = self.lib
+        self.engine._check(lib.hevcrecon_syntax_begin(self.h), "hevcrecon_syntax_begin")
+        ctus = pic.ctu_structs()
+        for a in range(pic.nctu):
+            self.engine._check(lib.hevcrecon_syntax_add_ctu(self.h, a, C.byref(ctus[a])), "hevcrecon_syntax_add_ctu")
+        self.engine._check(lib.hevcrecon_syntax_finish(self.h, C.byref(pic.pic_params)), "hevcrecon_syntax_finish")
+        self.poc = pic.poc
+        return self
+
+    def stats(self):
+        out = (C.c_int64 * 16)()
+        self.lib.hevcrecon_syntax_stats(self.h, out)
+        return list(out)
+
+    def algorithmic_bytes(self):
+        return int(self.lib.hevcrecon_syntax_algorithmic_bytes(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.hevcrecon_syntax_destroy(self.h)
+            self.h = None
+
+
+class Engine:
+    def __init__(self, seq_params, device=0, lib=None):
+        self.lib = lib if lib is not None else abi.load_library()
+        self.ctx = C.c_void_p()
+        rc = self.lib.hevcrecon_create(C.byref(self.ctx), device)
+        if rc:
+            raise EngineError("hevcrecon_create failed (%d): no usable GPU" % rc)
+        self.sp = seq_params
+        self._check(self.lib.hevcrecon_sequence_init(self.ctx, C.byref(seq_params)), "hevcrecon_sequence_init")
+        self.w, self.h = seq_params.width, seq_params.height
+
+    def _check(self, rc, what):
+        if rc:
+            msg = self.lib.hevcrecon_last_error(self.ctx)
+            raise EngineError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def close(self):
+        if self.ctx:
+            self.lib.hevcrecon_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def new_syntax(self):
+        h = C.c_void_p()
+        self._check(self.lib.hevcrecon_syntax_create(self.ctx, C.byref(h)), "hevcrecon_syntax_create")
+        return Syntax(self, h)
+
+    def reconstruct(self, syn, dst_pic_id):
+        self._check(self.lib.hevcrecon_reconstruct(self.ctx, syn.h, dst_pic_id), "hevcrecon_reconstruct")
+
+    def reconstruct_batch(self, syns, dst_pic_ids):
+        n = len(syns)
+        hs = (C.c_void_p * n)(*[s.h for s in syns])
+        ids = (C.c_int * n)(*dst_pic_ids)
+        self._check(self.lib.hevcrecon_reconstruct_batch(self.ctx, n, hs, ids), "hevcrecon_reconstruct_batch")
+
+    def _planes(self):
+        return [np.empty((self.h, self.w), np.int16), np.empty((self.h // 2, self.w // 2), np.int16),
+                np.empty((self.h // 2, self.w // 2), np.int16)]
+
+    def download(self, pic_id):
+        p = self._planes()
+        self._check(self.lib.hevcrecon_picture_download(self.ctx, pic_id, p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data,
+                                                        self.w, self.w // 2), "hevcrecon_picture_download")
+        return p
+
+    def keep_stages(self, on=True):
+        self._check(self.lib.hevcrecon_debug_keep_stages(self.ctx, 1 if on else 0), "hevcrecon_debug_keep_stages")
+
+    def download_stage(self, stage):
+        p = self._planes()
+        self._check(self.lib.hevcrecon_debug_download_stage(self.ctx, stage, p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data,
+                                                            self.w, self.w // 2), "hevcrecon_debug_download_stage")
+        return p
+
+    def upload(self, pic_id, poc, planes):
+        p = [np.ascontiguousarray(x, dtype=np.int16) for x in planes]
+        self._check(self.lib.hevcrecon_picture_upload(self.ctx, pic_id, poc, p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data,
+                                                      p[0].shape[1], p[1].shape[1]), "hevcrecon_picture_upload")
+
+    def release(self, pic_id):
+        self._check(self.lib.hevcrecon_picture_release(self.ctx, pic_id), "hevcrecon_picture_release")
+
+    def synchronize(self):
+        self._check(self.lib.hevcrecon_synchronize(self.ctx), "hevcrecon_synchronize")
+
+    def profile_enable(self, on=True):
+        self._check(self.lib.hevcrecon_profile_enable(self.ctx, 1 if on else 0), "hevcrecon_profile_enable")
+
+    def profile_read(self):
+        ms = (C.c_double * abi.NUM_KERNELS)()
+        n = (C.c_int64 * abi.NUM_KERNELS)()
+        self._check(self.lib.hevcrecon_profile_read(self.ctx, ms, n), "hevcrecon_profile_read")
+        return {self.lib.hevcrecon_kernel_name(i).decode(): (ms[i], n[i]) for i in range(abi.NUM_KERNELS)}
+
+
+def detached_syntax(seq_params, lib=None):
+    """Host-only packer object (no GPU needed): for host-logic tests."""
+    lib = lib if lib is not None else abi.load_library()
+    h = C.c_void_p()
+    rc = lib.hevcrecon_syntax_create_detached(C.byref(seq_params), C.byref(h))
+    if rc:
+        raise EngineError("hevcrecon_syntax_create_detached failed (%d)" % rc)
+
+    class _Host:
+        pass
+
+    host = _Host()
+    host.lib = lib
+    host._check = lambda rc, what: (_ for _ in ()).throw(EngineError("%s failed (%d)" % (what, rc))) if rc else None
+    return Syntax(host, h)

@@ -117,6 +117,16 @@ int hevcrecon_sequence_init(hevcrecon_ctx *ctx, const hevcrecon_seq_params *sp);
 int hevcrecon_syntax_create(hevcrecon_ctx *ctx, hevcrecon_syntax **out);
 void hevcrecon_syntax_destroy(hevcrecon_syntax *syn);
 
+/* Host-only syntax object (no GPU, no context): packs and can be inspected with hevcrecon_syntax_stats,
+ * cannot be reconstructed.  No counterpart in the reference; it lets the host-side packing logic be
+ * exercised on machines without a GPU. */
+int hevcrecon_syntax_create_detached(const hevcrecon_seq_params *sp, hevcrecon_syntax **out);
+
+/* Counters of the packed picture: out[0..3] coded transform blocks of size 4/8/16/32, [4] coded coefficients,
+ * [5] intra prediction blocks, [6] intra dependency levels, [7] reference samples read by inter prediction,
+ * [8] 4x4 records, [9] 4x4 records that are intra, [10] finished flag. */
+int hevcrecon_syntax_stats(const hevcrecon_syntax *syn, int64_t out[16]);
+
 /* Start a new picture in `syn` (drops whatever it held).  Stands where TDecTop::xDecodeSlice
  * obtains the picture buffer for a first slice (TLibDecoder/TDecTop.cpp:358-376). */
 int hevcrecon_syntax_begin(hevcrecon_syntax *syn);
@@ -149,8 +159,9 @@ int hevcrecon_reconstruct_batch(hevcrecon_ctx *ctx, int n, hevcrecon_syntax *con
 int hevcrecon_picture_download(hevcrecon_ctx *ctx, int pic_id, int16_t *y, int16_t *cb, int16_t *cr,
                                int stride_y, int stride_c);
 
-/* Intermediate planes of the most recent hevcrecon_reconstruct on this context, for stage-level
- * parity checks: stage 0 = before deblocking, 1 = after deblocking (before SAO). */
+/* Stage-level parity checks: after hevcrecon_debug_keep_stages(ctx, 1) every reconstruct call also keeps a
+ * copy of its first picture before deblocking (stage 0) and after deblocking, before SAO (stage 1). */
+int hevcrecon_debug_keep_stages(hevcrecon_ctx *ctx, int on);
 int hevcrecon_debug_download_stage(hevcrecon_ctx *ctx, int stage, int16_t *y, int16_t *cb, int16_t *cr,
                                    int stride_y, int stride_c);
 

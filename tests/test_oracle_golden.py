@@ -1,0 +1,59 @@
+"""The oracle (oracle/recon_ref.c) against the reference decoder's own outputs.
+
+Golden data (tests/golden):
+  *.syn.xz     syntax dumps written by the bridge decoder (oracle/hm_bridge.cpp, dump mode) while the
+               reference decoder (HM 9.1) decoded streams made by the reference encoder from the synthetic
+               clip of tools/gen_clip.py; each picture carries MD5s of the reference's picture before
+               deblocking, after deblocking and final.
+  hm_md5.json  the per-picture MD5s the unmodified reference decoder printed for the same streams, each
+               verified "(OK)" by it against the encoder's SEI digest.
+Generator: tools/make_fixtures.sh.
+"""
+import json
+import os
+
+import pytest
+
+from conftest import GOLDEN, STREAMS_240, bit_depths, load_golden
+from hevc_amd import syntax
+from oracle.refmodel import RefModel
+
+
+@pytest.mark.parametrize("stream", STREAMS_240)
+def test_oracle_matches_reference_all_stages(stream):
+    seq = load_golden(stream + "_416x240")
+    bd = bit_depths(seq)
+    ref = RefModel(seq.seq_params)
+    hm = json.load(open(os.path.join(GOLDEN, "hm_md5.json")))[stream + "_240"]
+    assert len(hm) == len(seq.pictures) == 9
+    for pic, (poc, my, mu, mv) in zip(seq.pictures, hm):
+        assert pic.poc == poc
+        ref.reconstruct(pic)
+        for stage in range(3):
+            planes = ref.download(stage, pic.pic_id)
+            for c in range(3):
+                assert syntax.plane_md5(planes[c], bd[c]) == pic.stage_md5[stage][c], (stream, poc, stage, c)
+        # the dump's final digest is the one the reference decoder printed and checked against the SEI
+        assert pic.stage_md5[2] == [my, mu, mv]
+    ref.close()
+
+
+def test_oracle_known_answers():
+    """Self-evident cases that need no reference: a lone DC coefficient, transform skip."""
+    import numpy as np
+
+    from hevc_amd import abi
+
+    seq = load_golden("intra_main_416x240", 1)
+    ref = RefModel(seq.seq_params)
+    pp = abi.PicParams()
+    for log2n in (2, 3, 4, 5):
+        n = 1 << log2n
+        coef = np.zeros((n, n), np.int32)
+        coef[0, 0] = 64
+        out = ref.inverse_tu(pp, coef, log2n, 0, 32, 0, 0)
+        assert (out == out[0, 0]).all() and out[0, 0] > 0  # flat block
+    coef = np.arange(16, dtype=np.int32).reshape(4, 4)
+    out = ref.inverse_tu(pp, coef, 2, 0, 28, 0, 1)  # QP 28: scale 64 << 4, shift 1 -> dq = coef * 512; tskip >> 5
+    assert (out == coef * 16).all()
+    ref.close()
