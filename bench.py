@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the picture-reconstruction engine on MI355X.
+
+Workload (BASELINE.json configs[2]): the 1920x1080, 60-frame random-access stream encoded by the reference
+encoder (cfg/encoder_randomaccess_main.cfg) from the synthetic clip of tools/gen_clip.py, as parsed by the
+reference decoder (tests/golden/randomaccess_main_1920x1080.syn.xz).  Each GPU reconstructs `--streams`
+independent copies of that stream (the stream-sharded multi-stream case), pictures of equal decoding
+position batched into one set of launches.  A step = one pass over all 60 pictures of every stream.
+The packed syntax is resident in HBM before the timed region starts; every final picture is MD5-checked
+against the reference decoder's digest after it.
+
+Prints one JSON line (rank 0).
+"""
+import argparse
+import copy
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hevc_amd import engine, syntax  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
+ID_STRIDE = 128         # picture ids of stream s are offset by s * ID_STRIDE
+
+
+def clone_for_stream(pic, s):
+    p = copy.copy(pic)
+    p.pic_params = type(pic.pic_params).from_buffer_copy(pic.pic_params)
+    for l in range(2):
+        for r in range(p.pic_params.num_ref[l]):
+            p.pic_params.ref_pic_id[l][r] = pic.pic_params.ref_pic_id[l][r] + s * ID_STRIDE
+    return p
+
+
+def kernel_bytes(seq, stats_list, sao_flags):
+    """Algorithmic bytes per kernel class for a list of pictures: the terms of
+    S*b*(1 store + 2 deblock + 2 SAO) + MC reference reads + 2*coefficients + 16 per 4x4 record,
+    attributed to the kernel that moves them."""
+    sp = seq.seq_params
+    b = 2 if sp.bit_depth_luma > 8 else 1
+    s_bytes = sp.width * sp.height * 3 // 2 * b
+    out = dict(k_inter=0, k_transform=0, k_intra=0, k_deblock_v=0, k_deblock_h=0, k_sao=0)
+    for st, sao in zip(stats_list, sao_flags):
+        n4, intra4 = st[8], st[9]
+        out["k_inter"] += (n4 - intra4) * 24 * b + st[7] * b + 16 * n4
+        out["k_intra"] += intra4 * 24 * b
+        out["k_transform"] += 2 * st[4]
+        out["k_deblock_v"] += s_bytes
+        out["k_deblock_h"] += s_bytes
+        out["k_sao"] += 2 * s_bytes if sao else 0
+    return out
+
+
+def cpu_baseline(seconds_target=12.0):
+    """Reference decoder (HM 9.1 TAppDecoder, -O3, one thread) on the same bitstream, host cores of this machine."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "TAppDecoder")
+    bits = os.path.join(ROOT, "tests", "golden", "randomaccess_main_1080.bin")
+    if os.path.exists(exe) and os.access(exe, os.X_OK) and os.path.exists(bits):
+        frames, t0 = 0, time.time()
+        while time.time() - t0 < seconds_target:
+            out = subprocess.run([exe, "-b", bits], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True).stdout.decode("latin1")
+            n = out.count("(OK)")
+            if n != 60:
+                raise RuntimeError("reference decoder did not report 60 matching pictures")
+            frames += n
+        dt = time.time() - t0
+        return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": 1, "kind": "reference",
+                "sample": "%d runs of the 60-frame 1080p RA stream through oracle/_ref/TAppDecoder (parse + reconstruction + MD5 check), %.1f s" % (frames // 60, dt)}
+    # the reference binary did not travel: time the C restatement (reconstruction only) instead
+    from oracle.refmodel import RefModel
+
+    seq = syntax.read_dump(os.path.join(ROOT, "tests", "golden", "randomaccess_main_1920x1080.syn.xz"), max_pictures=24)
+    ref = RefModel(seq.seq_params)
+    t0 = time.time()
+    for pic in seq.pictures:
+        ref.reconstruct(pic)
+    dt = time.time() - t0
+    return {"value": round(len(seq.pictures) / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "first %d pictures of the 1080p RA stream through oracle/recon_ref.c (reconstruction only), %.1f s" % (len(seq.pictures), dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=8, help="independent streams per GPU")
+    ap.add_argument("--fixture", default="randomaccess_main_1920x1080")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    seq = syntax.read_dump(os.path.join(ROOT, "tests", "golden", args.fixture + ".syn.xz"))
+    sp = seq.seq_params
+    npic, S = len(seq.pictures), args.streams
+    eng = engine.Engine(sp, device=local_rank)
+
+    # ---- pack every picture of every stream and make it resident in HBM (untimed) ----
+    syns = [[None] * S for _ in range(npic)]
+    stats, sao_flags = [], []
+    for t, pic in enumerate(seq.pictures):
+        pic.ctu_structs()
+        for s in range(S):
+            syns[t][s] = eng.new_syntax().pack(clone_for_stream(pic, s))
+        stats.append(syns[t][0].stats())
+        sao_flags.append(bool(pic.pic_params.sao_luma or pic.pic_params.sao_chroma))
+        pic.drop_ctypes()
+    ids = [[pic.pic_id + s * ID_STRIDE for s in range(S)] for pic in seq.pictures]
+    alg_bytes_stream = sum(syns[t][0].algorithmic_bytes() for t in range(npic))
+    eng.synchronize()
+
+    def one_step():
+        for t in range(npic):
+            eng.reconstruct_batch(syns[t], ids[t])
+
+    def sync():
+        eng.synchronize()
+        if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- parity: every final picture of the first and last stream against the reference decoder's MD5 ----
+    bd = [sp.bit_depth_luma, sp.bit_depth_chroma, sp.bit_depth_chroma]
+    for s in sorted({0, S - 1}):
+        for t, pic in enumerate(seq.pictures):
+            planes = eng.download(ids[t][s])
+            got = [syntax.plane_md5(planes[c], bd[c]) for c in range(3)]
+            if got != pic.stage_md5[2]:
+                raise SystemExit("bench: stream %d POC %d differs from the reference decoder's MD5" % (s, pic.poc))
+
+    # ---- per-kernel time with HIP events on the engine's stream (one extra, untimed step) ----
+    eng.profile_enable(True)
+    one_step()
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    kb = kernel_bytes(seq, stats, sao_flags)
+    kernels = {}
+    for name, nbytes in kb.items():
+        ms, launches = prof[name]
+        kernels[name] = {"ms_per_step": round(ms, 4), "launches": int(launches),
+                         "alg_gbps": round(nbytes * S / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}
+    dom = max(kb, key=lambda k: prof[k][0])
+    dom_ms, dom_launches = prof[dom]
+    achieved = kb[dom] * S / (dom_ms * 1e-3) / 1e9
+    gpu_ms = sum(prof[k][0] for k in kb)
+
+    frames_total = npic * S * args.steps * world
+    value = frames_total / elapsed
+    result = {
+        "metric": "1080p_ra_reconstructed_frames_per_s",
+        "value": round(value, 2),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8" if sp.bit_depth_luma <= 8 else "u16",
+        "data": "synthetic",
+        "config": {"workload": "%dx%d %d-frame RA stream (encoder_randomaccess_main.cfg), %d independent streams per GPU, "
+                               "stream-sharded, no collectives" % (sp.width, sp.height, npic, S),
+                   "streams_per_gpu": S, "frames_per_stream": npic, "md5_exact": True},
+        "recon_alg_gbps": round(alg_bytes_stream * S * args.steps / elapsed / 1e9, 2),
+        "recon_alg_gbps_gpu_time": round(alg_bytes_stream * S / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None,
+        "alg_bytes_per_frame": alg_bytes_stream // npic,
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                     "launches_per_step": int(dom_launches), "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 3)},
+        "kernels": kernels,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(result))
+    for row in syns:
+        for y in row:
+            y.close()
+    eng.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

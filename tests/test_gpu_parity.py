@@ -79,3 +79,23 @@ def test_errors_are_reported_not_crashed():
         eng.download(999)
     syn.close()
     eng.close()
+
+
+@pytest.mark.parametrize("stream", ["randomaccess_main", "randomaccess_he10", "intra_main"])
+def test_all_stages_md5_exact_1080p(stream):
+    """BASELINE configs 2-4 at full size: every picture's three stages against the MD5s of the reference
+    decoder's own pictures (before deblocking, after deblocking, final = the digest it checks against the SEI)."""
+    seq = load_golden(stream + "_1920x1080")
+    bd = bit_depths(seq)
+    eng = engine.Engine(seq.seq_params)
+    eng.keep_stages(True)
+    syn = eng.new_syntax()
+    for pic in seq.pictures:
+        syn.pack(pic)
+        eng.reconstruct(syn, pic.pic_id)
+        for stage in range(3):
+            got = eng.download(pic.pic_id) if stage == 2 else eng.download_stage(stage)
+            assert [syntax.plane_md5(got[c], bd[c]) for c in range(3)] == pic.stage_md5[stage], (stream, pic.poc, stage)
+        pic.drop_ctypes()
+    syn.close()
+    eng.close()

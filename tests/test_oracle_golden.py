@@ -57,3 +57,25 @@ def test_oracle_known_answers():
     out = ref.inverse_tu(pp, coef, 2, 0, 28, 0, 1)  # QP 28: scale 64 << 4, shift 1 -> dq = coef * 512; tskip >> 5
     assert (out == coef * 16).all()
     ref.close()
+
+
+STREAMS_1080 = [("randomaccess_main", 60), ("randomaccess_he10", 25), ("intra_main", 16)]
+
+
+@pytest.mark.parametrize("stream,npics", STREAMS_1080)
+def test_oracle_matches_reference_1080p(stream, npics):
+    """Full-size streams (BASELINE configs 2-4): every picture, every stage, against the reference decoder."""
+    seq = load_golden(stream + "_1920x1080")
+    bd = bit_depths(seq)
+    hm = json.load(open(os.path.join(GOLDEN, "hm_md5.json")))[stream + "_1080"]
+    assert len(seq.pictures) == len(hm) == npics
+    ref = RefModel(seq.seq_params)
+    for pic, (poc, my, mu, mv) in zip(seq.pictures, hm):
+        assert pic.poc == poc and pic.stage_md5[2] == [my, mu, mv]
+        ref.reconstruct(pic)
+        for stage in range(3):
+            planes = ref.download(stage, pic.pic_id)
+            for c in range(3):
+                assert syntax.plane_md5(planes[c], bd[c]) == pic.stage_md5[stage][c], (stream, poc, stage, c)
+        pic.drop_ctypes()
+    ref.close()
