@@ -151,10 +151,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- parity: every final picture of the first and last stream against the reference decoder's MD5 ----
+    # ---- parity: one more (untimed) pass, every final picture of the first and last stream against the
+    # reference decoder's MD5 right after its batch (the decoder recycles picture ids, so the check cannot wait)
     bd = [sp.bit_depth_luma, sp.bit_depth_chroma, sp.bit_depth_chroma]
-    for s in sorted({0, S - 1}):
-        for t, pic in enumerate(seq.pictures):
+    for t, pic in enumerate(seq.pictures):
+        eng.reconstruct_batch(syns[t], ids[t])
+        for s in sorted({0, S - 1}):
             planes = eng.download(ids[t][s])
             got = [syntax.plane_md5(planes[c], bd[c]) for c in range(3)]
             if got != pic.stage_md5[2]:

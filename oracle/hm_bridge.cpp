@@ -111,7 +111,6 @@ struct Bridge {
     sym(api.reconstruct, "hevcrecon_reconstruct");
     sym(api.picture_download, "hevcrecon_picture_download");
     if (api.create(&ctx, 0)) fail("hevcrecon_create");
-    if (api.syntax_create(ctx, &syn)) fail("hevcrecon_syntax_create");
   }
 
   int pic_id(TComPic *p) {
@@ -288,6 +287,7 @@ struct Bridge {
     hevcrecon_seq_params sp;
     fill_seq(pic, sp);
     if (api.sequence_init(ctx, &sp)) fail("hevcrecon_sequence_init");
+    if (!syn && api.syntax_create(ctx, &syn)) fail("hevcrecon_syntax_create");
     hevcrecon_pic_params pp;
     fill_pic(pic, pp);
     if (api.syntax_begin(syn)) fail("hevcrecon_syntax_begin");

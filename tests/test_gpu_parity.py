@@ -99,3 +99,23 @@ def test_all_stages_md5_exact_1080p(stream):
         pic.drop_ctypes()
     syn.close()
     eng.close()
+
+
+@pytest.mark.parametrize("bits,npics", [("lowdelay_P_main_240", 9), ("randomaccess_he10_240", 9), ("randomaccess_main_1080", 60)])
+def test_drop_in_behind_reference_decoder_cli(bits, npics):
+    """The reference decoder's own CLI with its reconstruction call sites redirected to the engine
+    (oracle/_ref/TAppDecoderBridge, HEVCRECON_MODE=engine): the reference parses, the GPU reconstructs, and the
+    reference's unchanged MD5 check must print (OK) for every picture and exit 0."""
+    import subprocess
+
+    from conftest import ROOT
+    from hevc_amd import abi
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "TAppDecoderBridge")
+    if not os.path.exists(exe):
+        pytest.skip("bridge decoder not built (needs the reference tree at build time)")
+    env = dict(os.environ, HEVCRECON_MODE="engine", HEVCRECON_LIB=abi.LIB_PATH)
+    r = subprocess.run([exe, "-b", os.path.join(GOLDEN, bits + ".bin")], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    out = r.stdout.decode("latin1")
+    assert r.returncode == 0, out[-2000:]
+    assert out.count("(OK)") == npics and "ERROR" not in out

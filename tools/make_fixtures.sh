@@ -1,0 +1,50 @@
+#!/bin/bash
+# Regenerates everything under tests/golden from scratch (needs the reference tree at /root/reference).
+#   1. synthetic clips (tools/gen_clip.py)
+#   2. bitstreams with the reference encoder (oracle/_ref/TAppEncoder, cfg files of the reference, QP 32, MD5 SEI on)
+#   3. syntax dumps + per-stage MD5s with the bridge decoder in dump mode (oracle/_ref/TAppDecoderBridge)
+#   4. xz-compressed fixtures and hm_md5.json (the MD5s the reference decoder printed, all "(OK)")
+# The 1080p encodes take 5-30 minutes each on one core; they run in parallel.
+set -euo pipefail
+root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
+cfg=/root/reference/cfg
+work="$root/work"
+mkdir -p "$work" && cd "$work"
+make -s -j8 -C "$root/oracle" ref dump
+python "$root/tools/gen_clip.py" 416 240 9 1234 c240.yuv
+python "$root/tools/gen_clip.py" 1920 1080 60 20240607 c1080.yuv
+E="$root/oracle/_ref/TAppEncoder"
+for c in lowdelay_P_main randomaccess_main randomaccess_he10 intra_main; do
+  $E -c $cfg/encoder_$c.cfg -i c240.yuv -wdt 416 -hgt 240 -fr 30 -f 9 -b ${c}_240.bin -o ${c}_240_rec.yuv --SEIpictureDigest=1 > ${c}_240.enc.log &
+done
+$E -c $cfg/encoder_randomaccess_main.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 60 -b ra_main_1080.bin -o /dev/null --SEIpictureDigest=1 > ra_main_1080.enc.log &
+$E -c $cfg/encoder_randomaccess_he10.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 25 -b ra_he10_1080.bin -o /dev/null --SEIpictureDigest=1 > ra_he10_1080.enc.log &
+$E -c $cfg/encoder_intra_main.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 16 -b intra_main_1080.bin -o /dev/null --SEIpictureDigest=1 > intra_main_1080.enc.log &
+wait
+D="$root/oracle/_ref/TAppDecoderBridge"
+for s in lowdelay_P_main_240 randomaccess_main_240 randomaccess_he10_240 intra_main_240 ra_main_1080 ra_he10_1080 intra_main_1080; do
+  HEVCRECON_MODE=dump HEVCRECON_DUMP=$s.syn $D -b $s.bin > $s.dec.log
+done
+cd "$root" && python - <<'PY'
+import json, re, shutil
+from hevc_amd import syntax
+names = {"lowdelay_P_main_240": "lowdelay_P_main_416x240", "randomaccess_main_240": "randomaccess_main_416x240",
+         "randomaccess_he10_240": "randomaccess_he10_416x240", "intra_main_240": "intra_main_416x240",
+         "ra_main_1080": "randomaccess_main_1920x1080", "ra_he10_1080": "randomaccess_he10_1920x1080",
+         "intra_main_1080": "intra_main_1920x1080"}
+keys = {"ra_main_1080": "randomaccess_main_1080", "ra_he10_1080": "randomaccess_he10_1080"}
+md5 = {}
+for src, dst in names.items():
+    syntax.strip_planes_and_compress("work/%s.syn" % src, "tests/golden/%s.syn.xz" % dst, preset=6)
+    rows = []
+    for line in open("work/%s.dec.log" % src, errors="replace"):
+        m = re.search(r"POC\s+(\d+).*\[MD5:([0-9a-f]{32}),([0-9a-f]{32}),([0-9a-f]{32}),\((\w+)\)\]", line)
+        if m:
+            assert m.group(5) == "OK"
+            rows.append([int(m.group(1)), m.group(2), m.group(3), m.group(4)])
+    md5[keys.get(src, src)] = rows
+json.dump(md5, open("tests/golden/hm_md5.json", "w"), indent=0)
+for b in ["lowdelay_P_main_240", "randomaccess_main_240", "randomaccess_he10_240", "intra_main_240"]:
+    shutil.copy("work/%s.bin" % b, "tests/golden/%s.bin" % b)
+shutil.copy("work/ra_main_1080.bin", "tests/golden/randomaccess_main_1080.bin")
+PY
