@@ -6,7 +6,10 @@
 //                                (the reference keeps these per CTU in z-order: TLibCommon/TComDataCU.h:122-204)
 //   * TuItem  tu[4][...]         one entry per coded transform block, grouped by size 4/8/16/32
 //   * int16   coeff[...]         coded coefficients, raster inside a block, blocks back to back
-//   * IntraItem intra[...]       one entry per intra prediction block, sorted by dependency level
+//   * IntraItem intra[...]       one entry per intra prediction block, grouped by CTU, inside a CTU by local
+//                                dependency level; IntraCtu ictu[...] one entry per CTU that holds intra blocks,
+//                                sorted by CTU wave (a CTU's wave is one more than the highest wave among its left,
+//                                above-left, above and above-right neighbours that hold intra blocks)
 //   * SaoCtu  sao[nCtu*3]        SAO parameters per CTU and component
 // Sample planes are uint8 for 8-bit sequences and uint16 otherwise, with no margin: kernels clamp
 // reference coordinates instead of reading the reference's 80-sample replicated border.
@@ -42,7 +45,7 @@ struct __attribute__((aligned(16))) Part4 {
 // TuItem.flags
 #define TU_TSKIP 0x01
 #define TU_DST 0x02
-#define TU_TO_RESI 0x04 /* intra block: write the residual to the residual buffer, else add it to the picture */
+#define TU_TO_RESI 0x04 /* intra block: write the residual to the residual planes, else add it to the picture */
 #define TU_BYPASS 0x08
 
 struct TuItem {
@@ -66,6 +69,14 @@ struct IntraItem {
   uint16_t avail_left; /* bit j: unit j of the left column, from the top; units [n/u, 2n/u) are below-left */
   uint16_t avail_above; /* bit i: unit i of the row above, from the left; units [n/u, 2n/u) are above-right */
   uint32_t resi_off;
+};
+
+struct IntraCtu {
+  uint32_t item_start; /* first IntraItem of this CTU */
+  uint32_t lvl_start;  /* first entry of this CTU in lvl_counts[] */
+  uint16_t n_items;
+  uint16_t n_lvl;      /* local dependency levels */
+  uint16_t cx, cy;     /* CTU position in CTUs */
 };
 
 struct SaoCtu {
@@ -95,10 +106,13 @@ struct PicJob {
   const TuItem *tu[4];
   int32_t n_tu[4];
   const int16_t *coeff;
-  int16_t *resi;
+  int16_t *resi[3]; /* residual of intra blocks, picture-shaped planes (same strides as the sample planes);
+                       only positions covered by a coded intra block are ever written or read */
   const IntraItem *intra;
-  const int32_t *level_off; /* n_levels + 1 entries */
-  int32_t n_levels;
+  const IntraCtu *ictu;
+  const uint16_t *lvl_counts; /* per CTU: number of intra blocks at each local level */
+  const int32_t *wave_off;    /* n_waves + 1 entries into ictu[] */
+  int32_t n_waves;
   const SaoCtu *sao;
   int32_t slice_type; /* 0 B, 1 P, 2 I */
   int32_t deblock_disable, beta_off_div2, tc_off_div2;

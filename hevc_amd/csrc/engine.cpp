@@ -45,8 +45,10 @@ struct hevcrecon_ctx {
   SeqInfo si;
   int pel_bytes = 1;
   size_t plane_off[3] = {0, 0, 0}, pic_bytes = 0;
+  size_t resi_off[3] = {0, 0, 0}, resi_bytes = 0;
   std::vector<DevPicture> pics;
   std::vector<DevPicture> work;
+  std::vector<void *> work_resi;  // per batch slot: int16 residual planes, same geometry as a picture
   DevPicture stage[2];
   bool keep_stages = false;
   PicJob *jobs_host = nullptr;  // pinned ring: kRing slots of HR_MAX_BATCH jobs
@@ -73,7 +75,7 @@ struct hevcrecon_syntax {
   size_t dev_cap = 0;
   char *host = nullptr;  // pinned staging
   size_t host_cap = 0;
-  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_resi = 0, off_intra = 0, off_level = 0, off_sao = 0;
+  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0;
   bool uploaded = false;
   std::string err;
 };
@@ -259,6 +261,10 @@ extern "C" void hevcrecon_destroy(hevcrecon_ctx *c) {
   drain_intervals(c);
   for (size_t i = 0; i < c->pics.size(); i++) free_picture(c->pics[i]);
   for (size_t i = 0; i < c->work.size(); i++) free_picture(c->work[i]);
+  for (size_t i = 0; i < c->work_resi.size(); i++) {
+    if (c->work_resi[i]) hipFree(c->work_resi[i]);
+    c->work_resi[i] = nullptr;
+  }
   free_picture(c->stage[0]);
   free_picture(c->stage[1]);
   for (size_t i = 0; i < c->event_pool.size(); i++) hipEventDestroy(c->event_pool[i]);
@@ -282,6 +288,10 @@ extern "C" int hevcrecon_sequence_init(hevcrecon_ctx *c, const hevcrecon_seq_par
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (size_t i = 0; i < c->pics.size(); i++) free_picture(c->pics[i]);
   for (size_t i = 0; i < c->work.size(); i++) free_picture(c->work[i]);
+  for (size_t i = 0; i < c->work_resi.size(); i++) {
+    if (c->work_resi[i]) hipFree(c->work_resi[i]);
+    c->work_resi[i] = nullptr;
+  }
   free_picture(c->stage[0]);
   free_picture(c->stage[1]);
   c->sp = *sp;
@@ -291,7 +301,12 @@ extern "C" int hevcrecon_sequence_init(hevcrecon_ctx *c, const hevcrecon_seq_par
   c->plane_off[0] = 0;
   c->plane_off[1] = align_up((size_t)c->si.stride_y * c->si.h * pb, 256);
   c->plane_off[2] = c->plane_off[1] + align_up((size_t)c->si.stride_c * c->si.ch * pb, 256);
-  c->pic_bytes = c->plane_off[2] + align_up((size_t)c->si.stride_c * c->si.ch * pb, 256);
+  // + 256: the packed reference fetch of k_inter reads whole dwords and may run a few bytes past the last row
+  c->pic_bytes = c->plane_off[2] + align_up((size_t)c->si.stride_c * c->si.ch * pb, 256) + 256;
+  c->resi_off[0] = 0;
+  c->resi_off[1] = align_up((size_t)c->si.stride_y * c->si.h * 2, 256);
+  c->resi_off[2] = c->resi_off[1] + align_up((size_t)c->si.stride_c * c->si.ch * 2, 256);
+  c->resi_bytes = c->resi_off[2] + align_up((size_t)c->si.stride_c * c->si.ch * 2, 256) + 256;
   c->have_seq = true;
   return 0;
 }
@@ -375,10 +390,11 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   for (int i = 0; i < 4; i++) s->off_tu[i] = place(k.tu[i].size() * sizeof(TuItem));
   s->off_coeff = place(k.coeff.size() * sizeof(int16_t));
   s->off_intra = place(k.intra.size() * sizeof(IntraItem));
-  s->off_level = place(k.level_off.size() * sizeof(int32_t));
+  s->off_ictu = place(k.ictu.size() * sizeof(IntraCtu));
+  s->off_lvlc = place(k.lvl_counts.size() * sizeof(uint16_t));
+  s->off_wave = place(k.wave_off.size() * sizeof(int32_t));
   s->off_sao = place(k.sao.size() * sizeof(SaoCtu));
   const size_t upload_bytes = off;
-  s->off_resi = place(k.coeff.size() * sizeof(int16_t));  // device-only scratch, same indexing as coeff
   const size_t total = off;
   if (s->dev_cap < total) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -401,7 +417,9 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   for (int i = 0; i < 4; i++) std::memcpy(s->host + s->off_tu[i], k.tu[i].data(), k.tu[i].size() * sizeof(TuItem));
   std::memcpy(s->host + s->off_coeff, k.coeff.data(), k.coeff.size() * sizeof(int16_t));
   std::memcpy(s->host + s->off_intra, k.intra.data(), k.intra.size() * sizeof(IntraItem));
-  std::memcpy(s->host + s->off_level, k.level_off.data(), k.level_off.size() * sizeof(int32_t));
+  std::memcpy(s->host + s->off_ictu, k.ictu.data(), k.ictu.size() * sizeof(IntraCtu));
+  std::memcpy(s->host + s->off_lvlc, k.lvl_counts.data(), k.lvl_counts.size() * sizeof(uint16_t));
+  std::memcpy(s->host + s->off_wave, k.wave_off.data(), k.wave_off.size() * sizeof(int32_t));
   std::memcpy(s->host + s->off_sao, k.sao.data(), k.sao.size() * sizeof(SaoCtu));
   HIPCHK(c, hipMemcpyAsync(s->dev, s->host, upload_bytes, hipMemcpyHostToDevice, c->stream));
   s->uploaded = true;
@@ -415,7 +433,9 @@ extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[16]
   for (int i = 0; i < 4; i++) out[i] = (int64_t)k.tu[i].size();
   out[4] = (int64_t)k.coeff.size();
   out[5] = (int64_t)k.intra.size();
-  out[6] = k.level_off.empty() ? 0 : (int64_t)k.level_off.size() - 1;
+  out[6] = k.wave_off.empty() ? 0 : (int64_t)k.wave_off.size() - 1;
+  out[11] = (int64_t)k.ictu.size();
+  out[12] = (int64_t)k.lvl_counts.size();
   out[7] = k.mc_ref_samples;
   out[8] = (int64_t)k.rec4.size();
   int64_t intra4 = 0;
@@ -452,15 +472,9 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
         for (int j = 0; j < n; j++)
           if (dst_ids[j] == id) return fail(c, "a picture of the batch references another picture of the batch");
       }
-    if (pp.slice_type != 2) {
-      // every reference index stored in the motion records must exist in the lists
-      const std::vector<Part4> &r4 = y->pk.rec4;
-      for (size_t k = 0; k < r4.size(); k++) {
-        if (r4[k].flags & P4_INTRA) continue;
-        if (r4[k].ref_idx[0] >= pp.num_ref[0] || r4[k].ref_idx[1] >= pp.num_ref[1] || (r4[k].ref_idx[0] < 0 && r4[k].ref_idx[1] < 0))
-          return fail(c, "motion record refers to a reference index outside the lists");
-      }
-    }
+    // every reference index stored in the motion records must exist in the lists (checked once, at pack time)
+    if (y->pk.inter_without_ref || y->pk.max_ref_idx[0] >= pp.num_ref[0] || y->pk.max_ref_idx[1] >= pp.num_ref[1])
+      return fail(c, "motion record refers to a reference index outside the lists");
   }
   // ---- device pictures ----
   for (int i = 0; i < n; i++) {
@@ -468,8 +482,11 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     if (alloc_picture(c, c->pics[dst_ids[i]])) return 1;
   }
   if ((int)c->work.size() < n) c->work.resize(n);
-  for (int i = 0; i < n; i++)
+  if ((int)c->work_resi.size() < n) c->work_resi.resize(n, nullptr);
+  for (int i = 0; i < n; i++) {
     if (alloc_picture(c, c->work[i])) return 1;
+    if (!c->work_resi[i]) HIPCHK(c, hipMalloc(&c->work_resi[i], c->resi_bytes));
+  }
   if (c->keep_stages)
     for (int k = 0; k < 2; k++)
       if (alloc_picture(c, c->stage[k])) return 1;
@@ -480,16 +497,21 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
   PicJob *jh = c->jobs_host + (size_t)slot * HR_MAX_BATCH;
   PicJob *jd = c->jobs_dev + (size_t)slot * HR_MAX_BATCH;
   int max_tu[4] = {0, 0, 0, 0}, max_levels = 0;
-  bool any_inter = false, any_deblock = false;
+  bool any_inter = false, any_deblock = false, any_sao = false;
   for (int i = 0; i < n; i++) {
     hevcrecon_syntax *y = syn[i];
     const PackedPicture &k = y->pk;
     PicJob &j = jh[i];
     std::memset(&j, 0, sizeof(j));
+    // Without SAO the deblocked picture IS the final picture: reconstruct straight into the DPB entry
+    // (k_sao then has nothing to do for it).  With SAO the working picture is separate because SAO
+    // classifies on deblocked samples only.
+    const bool sao_on = k.pp.sao_luma || k.pp.sao_chroma;
     for (int p = 0; p < 3; p++) {
-      j.rec[p] = c->work[i].p[p];
       j.out[p] = c->pics[dst_ids[i]].p[p];
+      j.rec[p] = sao_on ? c->work[i].p[p] : j.out[p];
     }
+    any_sao = any_sao || sao_on;
     for (int l = 0; l < 2; l++)
       for (int r = 0; r < k.pp.num_ref[l]; r++) {
         const DevPicture &rp = c->pics[k.pp.ref_pic_id[l][r]];
@@ -503,11 +525,13 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
       if (j.n_tu[t] > max_tu[t]) max_tu[t] = j.n_tu[t];
     }
     j.coeff = (const int16_t *)(y->dev + y->off_coeff);
-    j.resi = (int16_t *)(y->dev + y->off_resi);
+    for (int p = 0; p < 3; p++) j.resi[p] = (int16_t *)((char *)c->work_resi[i] + c->resi_off[p]);
     j.intra = (const IntraItem *)(y->dev + y->off_intra);
-    j.level_off = (const int32_t *)(y->dev + y->off_level);
-    j.n_levels = k.level_off.empty() ? 0 : (int)k.level_off.size() - 1;
-    if (j.n_levels > max_levels) max_levels = j.n_levels;
+    j.ictu = (const IntraCtu *)(y->dev + y->off_ictu);
+    j.lvl_counts = (const uint16_t *)(y->dev + y->off_lvlc);
+    j.wave_off = (const int32_t *)(y->dev + y->off_wave);
+    j.n_waves = k.wave_off.empty() ? 0 : (int)k.wave_off.size() - 1;
+    if (j.n_waves > max_levels) max_levels = j.n_waves;
     j.sao = (const SaoCtu *)(y->dev + y->off_sao);
     j.slice_type = k.pp.slice_type;
     j.deblock_disable = k.pp.deblocking_disable;
@@ -545,7 +569,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     for (int l = 0; l < max_levels; l++) {
       int mx = 0;
       for (int i = 0; i < n; i++) {
-        const std::vector<int32_t> &lo = syn[i]->pk.level_off;
+        const std::vector<int32_t> &lo = syn[i]->pk.wave_off;
         if (l + 1 < (int)lo.size()) mx = std::max(mx, lo[l + 1] - lo[l]);
       }
       if (mx > 0) {
@@ -556,7 +580,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
   }
   if (c->keep_stages) {
     Timed tm(c, K_COPY, 1);
-    HIPCHK(c, hipMemcpyAsync(c->stage[0].base, c->work[0].base, c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->stage[0].base, jh[0].rec[0], c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
   }
   if (any_deblock) {
     {
@@ -570,9 +594,9 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
   }
   if (c->keep_stages) {
     Timed tm(c, K_COPY, 1);
-    HIPCHK(c, hipMemcpyAsync(c->stage[1].base, c->work[0].base, c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->stage[1].base, jh[0].rec[0], c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
   }
-  {
+  if (any_sao) {
     Timed tm(c, K_SAO, 1);
     hr_launch(K_SAO, jd, n, s, c->stream, 0, 0);
   }

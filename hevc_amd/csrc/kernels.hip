@@ -9,7 +9,7 @@
 //                from the per-4x4 motion records, no PU list
 //   k_transform  one lane per column/row of a transform block: de-quantisation + 2-D inverse
 //                transform, result added to the picture (inter) or kept as residual (intra)
-//   k_intra      one wave per intra prediction block, one launch per dependency level
+//   k_intra      one workgroup per CTU (CTU staged in LDS, blocks level by level inside), one launch per CTU wave
 //   k_deblock    one lane per 4-sample edge segment; vertical edges, then horizontal edges
 //   k_sao        one lane per 4 samples, out of place (deblocked picture -> final picture)
 #ifdef HEVCRECON_EMULATE
@@ -145,6 +145,84 @@ __device__ __forceinline__ void interp_block(const pel_t *ref, int stride, int p
     for (int i = 0; i < BW; i++) out[j][i] = acc[j][i] >> 6;
 }
 
+// ---- byte-packed fast path for 8-bit pictures -------------------------------------------------------
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ unsigned hr_alignbyte(unsigned hi, unsigned lo, int sh) {
+  return (unsigned)((((unsigned long long)hi << 32) | lo) >> (8 * (sh & 3)));
+}
+__device__ __forceinline__ int hr_sdot4(unsigned a, unsigned b, int c) {
+  for (int k = 0; k < 4; k++) c += (int)(int8_t)(a >> (8 * k)) * (int)(int8_t)(b >> (8 * k));
+  return c;
+}
+#else
+__device__ __forceinline__ unsigned hr_alignbyte(unsigned hi, unsigned lo, int sh) { return __builtin_amdgcn_alignbyte(hi, lo, sh); }
+__device__ __forceinline__ int hr_sdot4(unsigned a, unsigned b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+#endif
+__device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
+  return (unsigned)(a & 255) | ((unsigned)(b & 255) << 8) | ((unsigned)(c & 255) << 16) | ((unsigned)(d & 255) << 24);
+}
+
+// Same arithmetic as interp_block for 8-bit samples, organised for the hardware: a row of the reference
+// window is fetched as aligned dwords and shifted into place (v_alignbyte), samples are biased to signed
+// bytes (x ^ 0x80 = x - 128) and the horizontal filter is two 4-way byte dot products.  Because the taps sum
+// to 64, sum(c_k * (p_k - 128)) = sum(c_k * p_k) - 8192, which IS the reference's 14-bit intermediate at
+// bit depth 8 (offset 8192, shift 0).  Rows whose vertical tap is zero are skipped when the vertical
+// fraction is zero.  Blocks whose window leaves the picture gather clamped bytes instead.
+template <int NT, int BW, int BH>
+__device__ __forceinline__ void interp_u8(const uint8_t *ref, int stride, int pw, int ph, int x0, int y0, unsigned tlo, unsigned thi,
+                                          const int *cy, bool v_identity, int out[BH][BW]) {
+  constexpr int HALF = NT / 2 - 1;
+  constexpr int NPIX = BW + NT - 1;
+  constexpr int NW = (NPIX + 3) / 4;
+  const int xs = x0 - HALF, ys = y0 - HALF;
+  const bool inside = xs >= 0 && xs + NPIX - 1 < pw && ys >= 0 && ys + BH + NT - 2 < ph;
+  const int a = xs & ~3, sh = xs & 3;
+  int acc[BH][BW];
+#pragma unroll
+  for (int j = 0; j < BH; j++)
+#pragma unroll
+    for (int i = 0; i < BW; i++) acc[j][i] = 0;
+#pragma unroll
+  for (int r = 0; r < BH + NT - 1; r++) {
+    if (v_identity && (r < HALF || r > HALF + BH - 1)) continue;
+    unsigned w[NW];
+    if (inside) {
+      const unsigned *rp = (const unsigned *)(ref + (size_t)(ys + r) * stride + a);
+      unsigned d[NW + 1];
+#pragma unroll
+      for (int k = 0; k <= NW; k++) d[k] = rp[k];
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[k] = hr_alignbyte(d[k + 1], d[k], sh);
+    } else {
+      const uint8_t *row = ref + (size_t)clip3i(0, ph - 1, ys + r) * stride;
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[k] = 0;
+#pragma unroll
+      for (int i = 0; i < NPIX; i++) w[i >> 2] |= (unsigned)row[clip3i(0, pw - 1, xs + i)] << (8 * (i & 3));
+    }
+#pragma unroll
+    for (int k = 0; k < NW; k++) w[k] ^= 0x80808080u;
+#pragma unroll
+    for (int i = 0; i < BW; i++) {
+      const unsigned lo = i ? hr_alignbyte(w[1], w[0], i) : w[0];
+      int h = hr_sdot4(lo, tlo, 0);
+      if (NT == 8) {
+        const unsigned hi = i ? hr_alignbyte(w[NW - 1], w[1], i) : w[1];
+        h = hr_sdot4(hi, thi, h);
+      }
+#pragma unroll
+      for (int j = 0; j < BH; j++) {
+        const int k = r - j;
+        if (k >= 0 && k < NT) acc[j][i] += cy[k] * h;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BH; j++)
+#pragma unroll
+    for (int i = 0; i < BW; i++) out[j][i] = acc[j][i] >> 6;
+}
+
 template <typename pel_t>
 __global__ __launch_bounds__(256) void k_inter(const PicJob *jobs, SeqInfo s) {
   const PicJob &J = jobs[blockIdx.y];
@@ -184,8 +262,12 @@ __global__ __launch_bounds__(256) void k_inter(const PicJob *jobs, SeqInfo s) {
       int tx[8], ty[8], o[4][4];
       luma_taps(mvx & 3, tx);
       luma_taps(mvy & 3, ty);
-      interp_block<pel_t, 8, 4, 4>(plane_c<pel_t>(J.ref[l][ri][0]), s.stride_y, s.w, s.h, x + (mvx >> 2), y + (mvy >> 2), tx, ty,
-                                   s.bd_y, o);
+      if constexpr (sizeof(pel_t) == 1)
+        interp_u8<8, 4, 4>((const uint8_t *)J.ref[l][ri][0], s.stride_y, s.w, s.h, x + (mvx >> 2), y + (mvy >> 2),
+                           pack4(tx[0], tx[1], tx[2], tx[3]), pack4(tx[4], tx[5], tx[6], tx[7]), ty, (mvy & 3) == 0, o);
+      else
+        interp_block<pel_t, 8, 4, 4>(plane_c<pel_t>(J.ref[l][ri][0]), s.stride_y, s.w, s.h, x + (mvx >> 2), y + (mvy >> 2), tx, ty,
+                                     s.bd_y, o);
 #pragma unroll
       for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -198,8 +280,12 @@ __global__ __launch_bounds__(256) void k_inter(const PicJob *jobs, SeqInfo s) {
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         int o[2][2];
-        interp_block<pel_t, 4, 2, 2>(plane_c<pel_t>(J.ref[l][ri][1 + c]), s.stride_c, s.cw, s.ch, (x >> 1) + (mvx >> 3),
-                                     (y >> 1) + (mvy >> 3), tx, ty, s.bd_c, o);
+        if constexpr (sizeof(pel_t) == 1)
+          interp_u8<4, 2, 2>((const uint8_t *)J.ref[l][ri][1 + c], s.stride_c, s.cw, s.ch, (x >> 1) + (mvx >> 3), (y >> 1) + (mvy >> 3),
+                             pack4(tx[0], tx[1], tx[2], tx[3]), 0u, ty, (mvy & 7) == 0, o);
+        else
+          interp_block<pel_t, 4, 2, 2>(plane_c<pel_t>(J.ref[l][ri][1 + c]), s.stride_c, s.cw, s.ch, (x >> 1) + (mvx >> 3),
+                                       (y >> 1) + (mvy >> 3), tx, ty, s.bd_c, o);
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -214,8 +300,15 @@ __global__ __launch_bounds__(256) void k_inter(const PicJob *jobs, SeqInfo s) {
     pel_t *dst = (pel_t *)J.rec[0] + (size_t)y * s.stride_y + x;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
+      int v[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) dst[i] = (pel_t)clip3i(0, maxv, (ly[j][i] + off) >> sh);
+      for (int i = 0; i < 4; i++) v[i] = clip3i(0, maxv, (ly[j][i] + off) >> sh);
+      if constexpr (sizeof(pel_t) == 1) {
+        *(unsigned *)dst = pack4(v[0], v[1], v[2], v[3]);  // x is a multiple of 4 and rows are 128-byte aligned
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) dst[i] = (pel_t)v[i];
+      }
       dst += s.stride_y;
     }
   }
@@ -331,7 +424,7 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
   }
   if (!live) return;
   if (it.flags & TU_TO_RESI) {
-    int16_t *o = J.resi + it.coeff_off + y * N;
+    int16_t *o = J.resi[comp] + (size_t)(it.y + y) * (comp ? s.stride_c : s.stride_y) + it.x;
 #pragma unroll
     for (int x = 0; x < N; x++) o[x] = (int16_t)res[x];
   } else {
@@ -345,191 +438,343 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_intra: intra prediction + residual add, one wave per block, one launch per dependency level
+// k_intra: intra prediction + residual add.  One workgroup per CTU, one launch per CTU wave.
 // ------------------------------------------------------------------------------------------------
+// The CTU's samples live in LDS together with the row above it (which reaches 32 samples into the
+// above-right CTU, as far as any block's above-right neighbours go) and the column left of it.  CTUs of one
+// wave are independent: everything they read from outside was finished by earlier launches (inter
+// prediction, earlier waves).  Inside the CTU the blocks are processed level by level (blocks of a level do
+// not depend on each other), one wave per block, a workgroup barrier between levels.
+//
 // Reference-sample array r[0..4n]: r[2n] is the corner, r[2n-1-j] the left column going down,
 // r[2n+1+i] the row above going right (TComPattern::initAdiPattern / fillReferenceSamples,
 // TLibCommon/TComPattern.cpp:213-602).  Availability comes per 4-luma-sample unit from the packer.
+#define IT_YW 100 /* luma tile row: x = -1 .. 96 (97 used) */
+#define IT_CW 52  /* chroma tile row: x = -1 .. 48 (49 used) */
+#define IT_MAX_ITEMS 384
+#define IT_MAX_LEVELS 96
+
 template <typename pel_t>
-__global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, int level) {
+__global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, int wave_idx) {
+  __shared__ uint16_t tile_y[65 * IT_YW];
+  __shared__ uint16_t tile_c[2][33 * IT_CW];
+  __shared__ int16_t resi_y[64 * 64];
+  __shared__ int16_t resi_c[2][32 * 32];
+  __shared__ IntraItem items_s[IT_MAX_ITEMS];
+  __shared__ uint16_t lvlc_s[IT_MAX_LEVELS];
   __shared__ int raw_s[4][132], ref_s[4][132], flt_s[4][132];
   const PicJob &J = jobs[blockIdx.y];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int first = 0, count = 0;
-  if (level < J.n_levels) {
-    first = J.level_off[level];
-    count = J.level_off[level + 1] - first;
-  }
-  const int idx = blockIdx.x * 4 + wv;
-  const bool live = idx < count;
-  IntraItem it;
-  it.x = it.y = 0;
-  it.log2n = 2;
-  it.comp = 0;
-  it.mode = 1;
-  it.flags = 0;
-  it.avail_left = it.avail_above = 0;
-  it.resi_off = 0;
-  if (live) it = J.intra[first + idx];
-  const int n = 1 << it.log2n, comp = it.comp;
-  const int sh = comp ? 1 : 0, us = 4 >> sh, nu = n / us;
-  const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
-  const int stride = comp ? s.stride_c : s.stride_y;
-  pel_t *plane = (pel_t *)J.rec[comp];
-  int *raw = raw_s[wv], *ref = ref_s[wv], *flt = flt_s[wv];
-  const int x0 = it.x, y0 = it.y, len = 4 * n + 1;
+  if (wave_idx >= J.n_waves) return;
+  const int first_ctu = J.wave_off[wave_idx];
+  if ((int)blockIdx.x >= J.wave_off[wave_idx + 1] - first_ctu) return;
+  const IntraCtu ci = J.ictu[first_ctu + blockIdx.x];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int ctux = ci.cx * 64, ctuy = ci.cy * 64;
 
-  // availability of the 4*nu+1 units in scan order (bottom-left ... corner ... top-right)
-  unsigned long long m = 0;
-  for (int j = 0; j < 2 * nu; j++)
-    if ((it.avail_left >> j) & 1) m |= 1ull << (2 * nu - 1 - j);
-  if (it.flags & IN_CORNER) m |= 1ull << (2 * nu);
-  for (int i = 0; i < 2 * nu; i++)
-    if ((it.avail_above >> i) & 1) m |= 1ull << (2 * nu + 1 + i);
-
-  // 1. gather
-  for (int i = lane; i < len; i += 64) {
-    int u, sx, sy;
-    if (i < 2 * n) {
-      u = i / us;
-      sx = x0 - 1;
-      sy = y0 + 2 * n - 1 - i;
-    } else if (i == 2 * n) {
-      u = 2 * nu;
-      sx = x0 - 1;
-      sy = y0 - 1;
-    } else {
-      u = 2 * nu + 1 + (i - 2 * n - 1) / us;
-      sx = x0 + (i - 2 * n - 1);
-      sy = y0 - 1;
-    }
-    int v = 0;
-    if (live && ((m >> u) & 1)) v = plane[(size_t)sy * stride + sx];
-    raw[i] = v;
-  }
-  __syncthreads();
-  // 2. substitution of unavailable units (TLibCommon/TComPattern.cpp:424-435,546-588)
-  for (int i = lane; i < len; i += 64) {
-    const int u = i < 2 * n ? i / us : (i == 2 * n ? 2 * nu : 2 * nu + 1 + (i - 2 * n - 1) / us);
-    int v;
-    if ((m >> u) & 1) {
-      v = raw[i];
-    } else if (m == 0) {
-      v = 1 << (bd - 1);
-    } else {
-      const unsigned long long below = m & ((1ull << u) - 1);
-      int src;
-      if (below) {
-        const int ub = 63 - __clzll((long long)below);  // nearest available unit before this one: take its last sample
-        src = ub < 2 * nu ? ub * us + us - 1 : (ub == 2 * nu ? 2 * n : 2 * n + 1 + (ub - 2 * nu - 1) * us + us - 1);
-      } else {
-        const int ua = __ffsll((long long)m) - 1;  // none before: first sample of the first available unit
-        src = ua < 2 * nu ? ua * us : (ua == 2 * nu ? 2 * n : 2 * n + 1 + (ua - 2 * nu - 1) * us);
-      }
-      v = raw[src];
-    }
-    ref[i] = v;
-  }
-  __syncthreads();
-  // 3. luma smoothing (TComPattern::getPredictorPtr :627-651 decides, :263-356 filters)
-  const int mode = it.mode;
-  bool use_flt = false;
-  if (comp == 0 && mode != 1) {
-    const int thr = it.log2n == 2 ? 10 : it.log2n == 3 ? 7 : it.log2n == 4 ? 1 : 0;
-    use_flt = min(iabs(mode - 10), iabs(mode - 26)) > thr;
-  }
-  if (use_flt) {
-    bool strong = false;
-    if (s.strong_intra && n >= 32) {
-      const int thr = 1 << (bd - 5);
-      strong = iabs(ref[0] + ref[2 * n] - 2 * ref[n]) < thr && iabs(ref[2 * n] + ref[4 * n] - 2 * ref[3 * n]) < thr;
-    }
-    for (int i = lane; i < len; i += 64) {
-      int v;
-      if (i == 0 || i == len - 1) {
-        v = ref[i];
-      } else if (strong) {
-        // bilinear between the three corners; n = 32 so the shift is log2(2n) = 6
-        if (i < 2 * n)
-          v = ((2 * n - i) * ref[0] + i * ref[2 * n] + n) >> 6;
-        else if (i == 2 * n)
-          v = ref[i];
-        else
-          v = ((2 * n - (i - 2 * n)) * ref[2 * n] + (i - 2 * n) * ref[4 * n] + n) >> 6;
-      } else {
-        v = (ref[i - 1] + 2 * ref[i] + ref[i + 1] + 2) >> 2;
-      }
-      flt[i] = v;
-    }
-  }
-  __syncthreads();
-  const int *r = use_flt ? flt : ref;
-  const int *cn = r + 2 * n;  // cn[0] corner, cn[-1-j] left[j], cn[1+i] above[i]
-  // DC value: wave reduction over the 2n neighbours (TLibCommon/TComPrediction.cpp:122-160)
-  int dcv = 0;
+  // ---- stage the CTU and its top / left borders in LDS ----
+  // An all-intra picture writes every sample of the CTU before reading it, so only the borders are needed.
+  const bool need_inside = J.slice_type != 2;
   {
-    int part = 0;
-    if (lane < 2 * n) part = lane < n ? cn[1 + lane] : cn[-1 - (lane - n)];
+    // All loads of the staging phase are independent of each other (one round trip to memory in total):
+    // interior rows as 16-byte vectors, the border row and column as single samples.
+    constexpr int VPR_Y = 64 * sizeof(pel_t) / 16;  // 16-byte vectors per luma row of the CTU
+    constexpr int SPV = 16 / sizeof(pel_t);         // samples per vector
+    if (need_inside) {
+      const pel_t *py = (const pel_t *)J.rec[0];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
-    dcv = (part + n) >> (it.log2n + 1);
-  }
-  // 4. prediction (TLibCommon/TComPrediction.cpp:183-390,691-763) + residual + store
-  const bool edge = comp == 0 && n <= 16;
-  const bool hor = mode >= 2 && mode < 18;
-  int angle = 0, inv = 0;
-  if (mode >= 2) {
-    const int a = hor ? -(mode - 10) : mode - 26;
-    const int aa = iabs(a);
-    const int at = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
-    inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
-    angle = a < 0 ? -at : at;
-  }
-  const int16_t *resi = J.resi + it.resi_off;
-  const bool has_resi = (it.flags & IN_HAS_RESI) != 0;
-  for (int p = lane; p < n * n; p += 64) {
-    const int py = p >> it.log2n, px = p & (n - 1);
-    int v;
-    if (mode == 0) {  // planar
-      const int l = cn[-1 - py], a = cn[1 + px];
-      const int hp = (l << it.log2n) + n + (px + 1) * (cn[1 + n] - l);
-      const int vp = (a << it.log2n) + (py + 1) * (cn[-1 - n] - a);
-      v = (hp + vp) >> (it.log2n + 1);
-    } else if (mode == 1) {  // DC
-      v = dcv;
-      if (edge) {
-        if (px == 0 && py == 0)
-          v = (cn[1] + cn[-1] + 2 * dcv + 2) >> 2;
-        else if (py == 0)
-          v = (cn[1 + px] + 3 * dcv + 2) >> 2;
-        else if (px == 0)
-          v = (cn[-1 - py] + 3 * dcv + 2) >> 2;
+      for (int k = 0; k < 64 * VPR_Y / 256; k++) {
+        const int v = tid + k * 256, ty = v / VPR_Y, tx = (v % VPR_Y) * SPV;
+        const int gx = ctux + tx, gy = ctuy + ty;
+        if (gx < s.w && gy < s.h) {
+          const uint4 q = *(const uint4 *)(py + (size_t)gy * s.stride_y + gx);
+          const unsigned w[4] = {q.x, q.y, q.z, q.w};
+          uint16_t *t = &tile_y[(ty + 1) * IT_YW + tx + 1];
+#pragma unroll
+          for (int e = 0; e < SPV; e++)
+            t[e] = sizeof(pel_t) == 1 ? (uint16_t)((w[e >> 2] >> (8 * (e & 3))) & 255) : (uint16_t)((w[e >> 1] >> (16 * (e & 1))) & 65535);
+        }
       }
-    } else {
-      // angular: vertical modes predict from the row above, horizontal modes are the same computation
-      // on the transposed block (main = left column)
-      const int k = hor ? px : py;  // index along the prediction direction
-      const int e = hor ? py : px;  // index across it
+      constexpr int VPR_C = 32 * sizeof(pel_t) / 16;
+#pragma unroll
+      for (int k = 0; k < (2 * 32 * VPR_C + 255) / 256; k++) {
+        const int v = tid + k * 256;
+        if (v < 2 * 32 * VPR_C) {
+          const int c = v / (32 * VPR_C), r = v % (32 * VPR_C), ty = r / VPR_C, tx = (r % VPR_C) * SPV;
+          const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
+          if (gx < s.cw && gy < s.ch) {
+            const uint4 q = *(const uint4 *)((const pel_t *)J.rec[1 + c] + (size_t)gy * s.stride_c + gx);
+            const unsigned w[4] = {q.x, q.y, q.z, q.w};
+            uint16_t *t = &tile_c[c][(ty + 1) * IT_CW + tx + 1];
+#pragma unroll
+            for (int e = 0; e < SPV; e++)
+              t[e] = sizeof(pel_t) == 1 ? (uint16_t)((w[e >> 2] >> (8 * (e & 3))) & 255) : (uint16_t)((w[e >> 1] >> (16 * (e & 1))) & 65535);
+          }
+        }
+      }
+    }
+    {
+      // border: luma row above (x = -1 .. 95) by threads 0..96, luma column left (y = 0 .. 63) by threads 128..191;
+      // chroma rows above (x = -1 .. 47) by threads 0..48 / 64..112, chroma columns left by threads 192..223 / 224..255
+      const pel_t *py = (const pel_t *)J.rec[0];
+      if (tid < 97) {
+        const int gx = ctux + tid - 1, gy = ctuy - 1;
+        if (gx >= 0 && gy >= 0 && gx < s.w) tile_y[tid] = py[(size_t)gy * s.stride_y + gx];
+      }
+      if (tid >= 128 && tid < 192) {
+        const int gx = ctux - 1, gy = ctuy + tid - 128;
+        if (gx >= 0 && gy < s.h) tile_y[(tid - 128 + 1) * IT_YW] = py[(size_t)gy * s.stride_y + gx];
+      }
+      {
+        const int c = tid >> 6, i = tid & 63;
+        if (c < 2 && i < 49) {
+          const int gx = (ctux >> 1) + i - 1, gy = (ctuy >> 1) - 1;
+          if (gx >= 0 && gy >= 0 && gx < s.cw) tile_c[c][i] = ((const pel_t *)J.rec[1 + c])[(size_t)gy * s.stride_c + gx];
+        }
+      }
+      if (tid >= 192) {
+        const int c = (tid - 192) >> 5, j = (tid - 192) & 31;
+        const int gx = (ctux >> 1) - 1, gy = (ctuy >> 1) + j;
+        if (gx >= 0 && gy < s.ch) tile_c[c][(j + 1) * IT_CW] = ((const pel_t *)J.rec[1 + c])[(size_t)gy * s.stride_c + gx];
+      }
+    }
+    // residual of the CTU's coded intra blocks (positions without one hold garbage and are never read)
+    for (int i = tid; i < 64 * 64 / 8; i += 256) {
+      const int ty = i >> 3, tx = (i & 7) * 8;
+      const int gx = ctux + tx, gy = ctuy + ty;
+      if (gx < s.w && gy < s.h) *(uint4 *)&resi_y[ty * 64 + tx] = *(const uint4 *)&J.resi[0][(size_t)gy * s.stride_y + gx];
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+      for (int i = tid; i < 32 * 32 / 4; i += 256) {
+        const int ty = i >> 3, tx = (i & 7) * 4;
+        const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
+        if (gx < s.cw && gy < s.ch) *(uint2 *)&resi_c[c][ty * 32 + tx] = *(const uint2 *)&J.resi[1 + c][(size_t)gy * s.stride_c + gx];
+      }
+    const int nit = ci.n_items < IT_MAX_ITEMS ? ci.n_items : IT_MAX_ITEMS;
+    for (int i = tid; i < nit; i += 256) items_s[i] = J.intra[ci.item_start + i];
+    for (int i = tid; i < ci.n_lvl && i < IT_MAX_LEVELS; i += 256) lvlc_s[i] = J.lvl_counts[ci.lvl_start + i];
+  }
+  __syncthreads();
+
+  int *raw = raw_s[wv], *ref = ref_s[wv], *flt = flt_s[wv];
+  int base = 0;
+  const int n_lvl = ci.n_lvl < IT_MAX_LEVELS ? ci.n_lvl : IT_MAX_LEVELS;
+  for (int lvl = 0; lvl < n_lvl; lvl++) {
+    const int cnt = lvlc_s[lvl];
+    for (int r0 = 0; r0 < cnt; r0 += 4) {
+      const int idx = r0 + wv;
+      const bool live = idx < cnt && base + idx < IT_MAX_ITEMS;
+      IntraItem it;
+      it.x = it.y = 0;
+      it.log2n = 2;
+      it.comp = 0;
+      it.mode = 1;
+      it.flags = 0;
+      it.avail_left = it.avail_above = 0;
+      it.resi_off = 0;
+      if (live) it = items_s[base + idx];
+      const int n = 1 << it.log2n, comp = it.comp;
+      const int sh = comp ? 1 : 0, us = 4 >> sh, nu = n / us;
+      const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
+      uint16_t *tile = comp ? tile_c[comp - 1] : tile_y;
+      const int tw = comp ? IT_CW : IT_YW;
+      const int x0 = it.x, y0 = it.y, len = 4 * n + 1;
+      // position of the block inside the tile (tile index 0 = sample -1 of the CTU)
+      const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
+
+      // availability of the 4*nu+1 units in scan order (bottom-left ... corner ... top-right)
+      unsigned long long m = 0;
+      for (int j = 0; j < 2 * nu; j++)
+        if ((it.avail_left >> j) & 1) m |= 1ull << (2 * nu - 1 - j);
+      if (it.flags & IN_CORNER) m |= 1ull << (2 * nu);
+      for (int i = 0; i < 2 * nu; i++)
+        if ((it.avail_above >> i) & 1) m |= 1ull << (2 * nu + 1 + i);
+
+      // 1. gather
+      for (int i = lane; i < len; i += 64) {
+        int u, sx, sy;  // unit, tile coordinates
+        if (i < 2 * n) {
+          u = i / us;
+          sx = tx0 - 1;
+          sy = ty0 + 2 * n - 1 - i;
+        } else if (i == 2 * n) {
+          u = 2 * nu;
+          sx = tx0 - 1;
+          sy = ty0 - 1;
+        } else {
+          u = 2 * nu + 1 + (i - 2 * n - 1) / us;
+          sx = tx0 + (i - 2 * n - 1);
+          sy = ty0 - 1;
+        }
+        int v = 0;
+        if (live && ((m >> u) & 1)) v = tile[sy * tw + sx];
+        raw[i] = v;
+      }
+      __syncthreads();
+      // 2. substitution of unavailable units (TLibCommon/TComPattern.cpp:424-435,546-588)
+      for (int i = lane; i < len; i += 64) {
+        const int u = i < 2 * n ? i / us : (i == 2 * n ? 2 * nu : 2 * nu + 1 + (i - 2 * n - 1) / us);
+        int v;
+        if ((m >> u) & 1) {
+          v = raw[i];
+        } else if (m == 0) {
+          v = 1 << (bd - 1);
+        } else {
+          const unsigned long long below = m & ((1ull << u) - 1);
+          int src;
+          if (below) {
+            const int ub = 63 - __clzll((long long)below);  // nearest available unit before this one: take its last sample
+            src = ub < 2 * nu ? ub * us + us - 1 : (ub == 2 * nu ? 2 * n : 2 * n + 1 + (ub - 2 * nu - 1) * us + us - 1);
+          } else {
+            const int ua = __ffsll((long long)m) - 1;  // none before: first sample of the first available unit
+            src = ua < 2 * nu ? ua * us : (ua == 2 * nu ? 2 * n : 2 * n + 1 + (ua - 2 * nu - 1) * us);
+          }
+          v = raw[src];
+        }
+        ref[i] = v;
+      }
+      __syncthreads();
+      // 3. luma smoothing (TComPattern::getPredictorPtr :627-651 decides, :263-356 filters)
+      const int mode = it.mode;
+      bool use_flt = false;
+      if (comp == 0 && mode != 1) {
+        const int thr = it.log2n == 2 ? 10 : it.log2n == 3 ? 7 : it.log2n == 4 ? 1 : 0;
+        use_flt = min(iabs(mode - 10), iabs(mode - 26)) > thr;
+      }
+      if (use_flt) {
+        bool strong = false;
+        if (s.strong_intra && n >= 32) {
+          const int thr = 1 << (bd - 5);
+          strong = iabs(ref[0] + ref[2 * n] - 2 * ref[n]) < thr && iabs(ref[2 * n] + ref[4 * n] - 2 * ref[3 * n]) < thr;
+        }
+        for (int i = lane; i < len; i += 64) {
+          int v;
+          if (i == 0 || i == len - 1) {
+            v = ref[i];
+          } else if (strong) {
+            // bilinear between the three corners; n = 32 so the shift is log2(2n) = 6
+            if (i < 2 * n)
+              v = ((2 * n - i) * ref[0] + i * ref[2 * n] + n) >> 6;
+            else if (i == 2 * n)
+              v = ref[i];
+            else
+              v = ((2 * n - (i - 2 * n)) * ref[2 * n] + (i - 2 * n) * ref[4 * n] + n) >> 6;
+          } else {
+            v = (ref[i - 1] + 2 * ref[i] + ref[i + 1] + 2) >> 2;
+          }
+          flt[i] = v;
+        }
+      }
+      __syncthreads();
+      const int *r = use_flt ? flt : ref;
+      const int *cn = r + 2 * n;  // cn[0] corner, cn[-1-j] left[j], cn[1+i] above[i]
+      // DC value: wave reduction over the 2n neighbours (TLibCommon/TComPrediction.cpp:122-160)
+      int dcv = 0;
+      {
+        int part = 0;
+        if (lane < 2 * n) part = lane < n ? cn[1 + lane] : cn[-1 - (lane - n)];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+        dcv = (part + n) >> (it.log2n + 1);
+      }
+      // 4. prediction (TLibCommon/TComPrediction.cpp:183-390,691-763) + residual + store
+      const bool edge = comp == 0 && n <= 16;
+      const bool hor = mode >= 2 && mode < 18;
+      int angle = 0, inv = 0;
+      if (mode >= 2) {
+        const int a = hor ? -(mode - 10) : mode - 26;
+        const int aa = iabs(a);
+        const int at = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
+        inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
+        angle = a < 0 ? -at : at;
+      }
+      // residual tile: same geometry as the sample tile without its border row / column
+      const int16_t *resi = comp ? resi_c[comp - 1] : resi_y;
+      const int rw = comp ? 32 : 64;
+      const bool has_resi = (it.flags & IN_HAS_RESI) != 0;
+      for (int p = lane; p < n * n; p += 64) {
+        const int py = p >> it.log2n, px = p & (n - 1);
+        int v;
+        if (mode == 0) {  // planar
+          const int l = cn[-1 - py], a = cn[1 + px];
+          const int hp = (l << it.log2n) + n + (px + 1) * (cn[1 + n] - l);
+          const int vp = (a << it.log2n) + (py + 1) * (cn[-1 - n] - a);
+          v = (hp + vp) >> (it.log2n + 1);
+        } else if (mode == 1) {  // DC
+          v = dcv;
+          if (edge) {
+            if (px == 0 && py == 0)
+              v = (cn[1] + cn[-1] + 2 * dcv + 2) >> 2;
+            else if (py == 0)
+              v = (cn[1 + px] + 3 * dcv + 2) >> 2;
+            else if (px == 0)
+              v = (cn[-1 - py] + 3 * dcv + 2) >> 2;
+          }
+        } else {
+          // angular: vertical modes predict from the row above, horizontal modes are the same computation
+          // on the transposed block (main = left column)
+          const int k = hor ? px : py;  // index along the prediction direction
+          const int e = hor ? py : px;  // index across it
 #define MAIN(i) (hor ? cn[-(i)] : cn[(i)])
 #define SIDE(i) (hor ? cn[(i)] : cn[-(i)])
-      if (angle == 0) {
-        v = MAIN(e + 1);
-        if (edge && e == 0) v = clip3i(0, maxv, v + ((SIDE(k + 1) - SIDE(0)) >> 1));
-      } else {
-        const int pos = (k + 1) * angle;
-        const int di = pos >> 5, df = pos & 31;
-        const int i0 = e + di + 1, i1 = i0 + 1;
-        // negative indices address the side reference projected onto the main one
-        const int a0 = i0 >= 0 ? MAIN(i0) : SIDE((128 - i0 * inv) >> 8);
-        const int a1 = i1 >= 0 ? MAIN(i1) : SIDE((128 - i1 * inv) >> 8);
-        v = df ? ((32 - df) * a0 + df * a1 + 16) >> 5 : a0;
-      }
+          if (angle == 0) {
+            v = MAIN(e + 1);
+            if (edge && e == 0) v = clip3i(0, maxv, v + ((SIDE(k + 1) - SIDE(0)) >> 1));
+          } else {
+            const int pos = (k + 1) * angle;
+            const int di = pos >> 5, df = pos & 31;
+            const int i0 = e + di + 1, i1 = i0 + 1;
+            // negative indices address the side reference projected onto the main one
+            const int a0 = i0 >= 0 ? MAIN(i0) : SIDE((128 - i0 * inv) >> 8);
+            const int a1 = i1 >= 0 ? MAIN(i1) : SIDE((128 - i1 * inv) >> 8);
+            v = df ? ((32 - df) * a0 + df * a1 + 16) >> 5 : a0;
+          }
 #undef MAIN
 #undef SIDE
+        }
+        if (live) {
+          if (has_resi) v += resi[(ty0 - 1 + py) * rw + tx0 - 1 + px];
+          tile[(ty0 + py) * tw + tx0 + px] = (uint16_t)clip3i(0, maxv, v);
+        }
+      }
     }
-    if (live) {
-      if (has_resi) v += resi[p];
-      plane[(size_t)(y0 + py) * stride + x0 + px] = (pel_t)clip3i(0, maxv, v);
+    base += cnt;
+    __syncthreads();  // the next level reads what this one wrote into the tile
+  }
+  // ---- write the CTU back (in P/B pictures the inter samples staged above go back unchanged) ----
+  {
+    pel_t *py = (pel_t *)J.rec[0];
+    for (int i = tid; i < 64 * 64 / 4; i += 256) {
+      const int ty = i >> 4, tx = (i & 15) * 4;
+      const int gx = ctux + tx, gy = ctuy + ty;
+      if (gx < s.w && gy < s.h) {
+        const uint16_t *t = &tile_y[(ty + 1) * IT_YW + tx + 1];
+        pel_t *o = py + (size_t)gy * s.stride_y + gx;
+        if constexpr (sizeof(pel_t) == 1) {
+          *(unsigned *)o = pack4(t[0], t[1], t[2], t[3]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) o[k] = (pel_t)t[k];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      pel_t *pc = (pel_t *)J.rec[1 + c];
+      for (int i = tid; i < 32 * 32 / 4; i += 256) {
+        const int ty = i >> 3, tx = (i & 7) * 4;
+        const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
+        if (gx < s.cw && gy < s.ch) {
+          const uint16_t *t = &tile_c[c][(ty + 1) * IT_CW + tx + 1];
+          pel_t *o = pc + (size_t)gy * s.stride_c + gx;
+          if constexpr (sizeof(pel_t) == 1) {
+            *(unsigned *)o = pack4(t[0], t[1], t[2], t[3]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) o[k] = (pel_t)t[k];
+          }
+        }
+      }
     }
   }
 }
@@ -685,49 +930,98 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
 // blockIdx.z = component.  One lane handles 4 consecutive samples of a row.
 template <typename pel_t>
 __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
-  const PicJob &J = jobs[blockIdx.y];
-  const int comp = blockIdx.z;
+  // grid: x = 64-lane chunks of a row (16 samples per lane), y = groups of 4 rows, z = picture * 3 + component
+  const PicJob &J = jobs[blockIdx.z / 3];
+  const int comp = blockIdx.z % 3;
+  if (J.rec[comp] == J.out[comp]) return;  // picture without SAO: reconstructed in place, nothing to do
   const int pw = comp ? s.cw : s.w, ph = comp ? s.ch : s.h, stride = comp ? s.stride_c : s.stride_y;
   const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
-  const int qw = pw >> 2;
-  const int gid = blockIdx.x * 256 + threadIdx.x;
-  const int qx = gid % qw, y = gid / qw;
-  if (y >= ph) return;
-  const int x = qx * 4;
+  const int x = (blockIdx.x * 64 + threadIdx.x) * 16, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= pw || y >= ph) return;
   const pel_t *src = (const pel_t *)J.rec[comp];
   pel_t *dst = (pel_t *)J.out[comp];
   const int csh = comp ? 5 : 6;
   const SaoCtu sp = J.sao[((size_t)(y >> csh) * s.ctus_w + (x >> csh)) * 3 + comp];
   const bool on = (comp ? J.sao_chroma : J.sao_luma) && sp.type >= 0;
   const int inc = bd > 10 ? bd - 10 : 0;
-  int v[4];
   const pel_t *row = src + (size_t)y * stride;
+  // samples x-1 .. x+16 of one row.  Reads past the picture width stay inside the padded row (or the slack
+  // after the last plane) and are never used: such neighbours make the sample a border sample.
+  auto fetch18 = [&](const pel_t *rp, int o[18]) {
+    if constexpr (sizeof(pel_t) == 1) {
+      const uint4 m = *(const uint4 *)(rp + x);
+      const unsigned l = x > 0 ? *(const unsigned *)(rp + x - 4) : 0u;
+      const unsigned r = *(const unsigned *)(rp + x + 16);
+      const unsigned w[4] = {m.x, m.y, m.z, m.w};
+      o[0] = (int)(l >> 24);
 #pragma unroll
-  for (int i = 0; i < 4; i++) v[i] = row[x + i];
-  if (on) {
-    if (sp.type == 4) {
+      for (int k = 0; k < 4; k++)
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int k = ((v[i] >> (bd - 5)) - sp.band) & 31;
-        const int o = k == 0 ? sp.offset[0] : k == 1 ? sp.offset[1] : k == 2 ? sp.offset[2] : k == 3 ? sp.offset[3] : 0;
-        v[i] = clip3i(0, maxv, v[i] + (o << inc));
-      }
+        for (int i = 0; i < 4; i++) o[1 + 4 * k + i] = (int)((w[k] >> (8 * i)) & 255);
+      o[17] = (int)(r & 255);
     } else {
-      const int dx = sp.type == 1 ? 0 : (sp.type == 3 ? -1 : 1), dy = sp.type == 0 ? 0 : 1;
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int ax = x + i - dx, ay = y - dy, bx = x + i + dx, by = y + dy;
-        if (ax < 0 || bx < 0 || ax >= pw || bx >= pw || ay < 0 || by >= ph) continue;  // picture border samples stay
-        const int a = src[(size_t)ay * stride + ax], b = src[(size_t)by * stride + bx];
-        const int e = (v[i] > a) - (v[i] < a) + (v[i] > b) - (v[i] < b);  // -2..2
-        const int o = e == -2 ? sp.offset[0] : e == -1 ? sp.offset[1] : e == 1 ? sp.offset[2] : e == 2 ? sp.offset[3] : 0;
-        v[i] = clip3i(0, maxv, v[i] + (o << inc));
+      for (int i = 0; i < 18; i++) {
+        const int xx = x + i - 1;
+        o[i] = (xx >= 0 && xx < pw) ? (int)rp[xx] : 0;
       }
+    }
+  };
+  int cur[18], v[16];
+  fetch18(row, cur);
+  if (on && sp.type < 4) {
+    // edge offset: a = neighbour towards (-dx,-dy), b = towards (+dx,+dy); picture-border samples stay as they are
+    const int dx = sp.type == 1 ? 0 : (sp.type == 3 ? -1 : 1), dy = sp.type == 0 ? 0 : 1;
+    int up[18], dn[18];
+    const bool rows_ok = dy == 0 || (y > 0 && y + 1 < ph);
+    if (dy && rows_ok) {
+      fetch18(row - stride, up);
+      fetch18(row + stride, dn);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 18; i++) up[i] = dn[i] = cur[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int c = cur[i + 1];
+      const int a = dx == 0 ? up[i + 1] : (dx > 0 ? up[i] : up[i + 2]);
+      const int b = dx == 0 ? dn[i + 1] : (dx > 0 ? dn[i + 2] : dn[i]);
+      const bool border = !rows_ok || x + i - dx < 0 || x + i - dx >= pw || x + i + dx < 0 || x + i + dx >= pw;
+      const int e = (c > a) - (c < a) + (c > b) - (c < b);  // -2..2
+      const int o = e == -2 ? sp.offset[0] : e == -1 ? sp.offset[1] : e == 1 ? sp.offset[2] : e == 2 ? sp.offset[3] : 0;
+      v[i] = border ? c : clip3i(0, maxv, c + (o << inc));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      int c = cur[i + 1];
+      if (on) {  // band offset
+        const int k = ((c >> (bd - 5)) - sp.band) & 31;
+        const int o = k == 0 ? sp.offset[0] : k == 1 ? sp.offset[1] : k == 2 ? sp.offset[2] : k == 3 ? sp.offset[3] : 0;
+        c = clip3i(0, maxv, c + (o << inc));
+      }
+      v[i] = c;
     }
   }
   pel_t *orow = dst + (size_t)y * stride + x;
+  if constexpr (sizeof(pel_t) == 1) {
+    if (x + 16 <= pw) {
+      uint4 o4;
+      o4.x = pack4(v[0], v[1], v[2], v[3]);
+      o4.y = pack4(v[4], v[5], v[6], v[7]);
+      o4.z = pack4(v[8], v[9], v[10], v[11]);
+      o4.w = pack4(v[12], v[13], v[14], v[15]);
+      *(uint4 *)orow = o4;
+    } else {
 #pragma unroll
-  for (int i = 0; i < 4; i++) orow[i] = (pel_t)v[i];
+      for (int q = 0; q < 4; q++)
+        if (x + 4 * q < pw) *(unsigned *)(orow + 4 * q) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+      if (x + i < pw) orow[i] = (pel_t)v[i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -752,8 +1046,8 @@ static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, 
       break;
     }
     case K_INTRA:
-      // arg = level, arg2 = max number of blocks in that level over the batch
-      LAUNCH(k_intra<pel_t>, dim3((arg2 + 3) / 4, n), dim3(256), st, jobs, s, arg);
+      // arg = CTU wave, arg2 = max number of CTUs in that wave over the batch
+      LAUNCH(k_intra<pel_t>, dim3(arg2, n), dim3(256), st, jobs, s, arg);
       break;
     case K_DEBLOCK_V:
       LAUNCH((k_deblock<pel_t, 0>), dim3(((s.w / 8) * s.uh + 255) / 256, n), dim3(256), st, jobs, s);
@@ -762,7 +1056,7 @@ static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, 
       LAUNCH((k_deblock<pel_t, 1>), dim3(((s.h / 8) * s.uw + 255) / 256, n), dim3(256), st, jobs, s);
       break;
     case K_SAO:
-      LAUNCH(k_sao<pel_t>, dim3(((s.w / 4) * s.h + 255) / 256, n, 3), dim3(256), st, jobs, s);
+      LAUNCH(k_sao<pel_t>, dim3((s.w / 16 + 64) / 64, (s.h + 3) / 4, n * 3), dim3(64, 4), st, jobs, s);
       break;
     default:
       break;

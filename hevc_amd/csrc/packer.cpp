@@ -45,12 +45,17 @@ void PackedPicture::begin(const SeqInfo &s) {
   for (int i = 0; i < 4; i++) tu[i].clear();
   coeff.clear();
   intra.clear();
-  intra_level.clear();
-  level_off.clear();
+  ictu.clear();
+  ictu_wave.clear();
+  lvl_counts.clear();
+  wave_off.clear();
+  ctu_wave.assign((size_t)s.ctus_w * s.ctus_h, 0);
   sao.assign((size_t)s.ctus_w * s.ctus_h * 3, SaoCtu());
   lvl_y.assign((size_t)s.uw * s.uh, 0);
   lvl_c.assign((size_t)s.uw * s.uh, 0);
   mc_ref_samples = 0;
+  max_ref_idx[0] = max_ref_idx[1] = -1;
+  inter_without_ref = false;
   next_ctu = 0;
   finished = false;
   error.clear();
@@ -73,7 +78,38 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
     s.band = (int8_t)ctu->sao_subtype[c];
     for (int i = 0; i < 4; i++) s.offset[i] = (int8_t)ctu->sao_offset[c][i];
   }
-  walk_cu(ctu, (addr % seq.ctus_w) * 64, (addr / seq.ctus_w) * 64, 0, 0);
+  ctu_items.clear();
+  ctu_item_lvl.clear();
+  const int cx = addr % seq.ctus_w, cy = addr / seq.ctus_w;
+  walk_cu(ctu, cx * 64, cy * 64, 0, 0);
+  if (!ctu_items.empty()) {
+    // blocks of one local level are independent of each other: order the CTU's blocks by level
+    int nlev = 0;
+    for (size_t i = 0; i < ctu_item_lvl.size(); i++) nlev = std::max<int>(nlev, ctu_item_lvl[i]);
+    std::vector<int> start(nlev + 2, 0);
+    for (size_t i = 0; i < ctu_item_lvl.size(); i++) start[ctu_item_lvl[i] + 1]++;
+    IntraCtu ic;
+    ic.item_start = (uint32_t)intra.size();
+    ic.lvl_start = (uint32_t)lvl_counts.size();
+    ic.n_items = (uint16_t)ctu_items.size();
+    ic.n_lvl = (uint16_t)nlev;
+    ic.cx = (uint16_t)cx;
+    ic.cy = (uint16_t)cy;
+    for (int l = 1; l <= nlev; l++) lvl_counts.push_back((uint16_t)start[l + 1]);
+    for (int l = 1; l <= nlev + 1; l++) start[l] += start[l - 1];
+    intra.resize(ic.item_start + ctu_items.size());
+    for (size_t i = 0; i < ctu_items.size(); i++) intra[ic.item_start + start[ctu_item_lvl[i]]++] = ctu_items[i];
+    // wave: after every neighbouring CTU whose intra blocks this CTU may read
+    int wave = 0;
+    const int nb[4][2] = {{-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+    for (int k = 0; k < 4; k++) {
+      const int nx = cx + nb[k][0], ny = cy + nb[k][1];
+      if (nx >= 0 && ny >= 0 && nx < seq.ctus_w) wave = std::max<int>(wave, ctu_wave[(size_t)ny * seq.ctus_w + nx]);
+    }
+    ctu_wave[addr] = (uint16_t)(wave + 1);
+    ictu.push_back(ic);
+    ictu_wave.push_back((uint16_t)(wave + 1));
+  }
   return error.empty();
 }
 
@@ -112,6 +148,8 @@ void PackedPicture::walk_cu(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy,
     if (!intra) {
       int nref = (p.ref_idx[0] >= 0) + (p.ref_idx[1] >= 0);
       mc_ref_samples += 24 * nref;  // 16 luma + 2 x 4 chroma samples per reference read
+      if (nref == 0) inter_without_ref = true;
+      for (int l = 0; l < 2; l++) max_ref_idx[l] = std::max<int>(max_ref_idx[l], p.ref_idx[l]);
     }
   }
   if ((ctu->ipcm && ctu->ipcm[z]) || (ctu->transquant_bypass && ctu->transquant_bypass[z])) {
@@ -183,6 +221,12 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
   // A neighbouring unit can be used iff it is inside the picture and precedes this block in coding order
   // (TComPattern::is*Available over TComDataCU::getPU*, TLibCommon/TComPattern.cpp:653-830,
   // TLibCommon/TComDataCU.cpp:1141-1589, for one slice / one tile / unconstrained intra prediction).
+  // Local dependency level: one more than the highest level among the intra blocks OF THE SAME CTU that cover
+  // an available neighbouring unit (blocks of other CTUs are finished before this CTU starts: CTU waves).
+  const int my_cx = ux0 >> 4, my_cy = uy0 >> 4;
+  auto level_at = [&](int ux, int uy) -> int {
+    return ((ux >> 4) == my_cx && (uy >> 4) == my_cy) ? lvl[(size_t)uy * seq.uw + ux] : 0;
+  };
   int level = 0;
   uint16_t left = 0, above = 0;
   int corner = 0;
@@ -190,19 +234,19 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
     const int ux = ux0 - 1, uy = uy0 + j;
     if (ux >= 0 && uy < seq.uh && coding_order(ux, uy) < cur) {
       left |= (uint16_t)(1u << j);
-      level = std::max<int>(level, lvl[(size_t)uy * seq.uw + ux]);
+      level = std::max<int>(level, level_at(ux, uy));
     }
   }
   for (int i = 0; i < 2 * nu; i++) {
     const int ux = ux0 + i, uy = uy0 - 1;
     if (uy >= 0 && ux < seq.uw && coding_order(ux, uy) < cur) {
       above |= (uint16_t)(1u << i);
-      level = std::max<int>(level, lvl[(size_t)uy * seq.uw + ux]);
+      level = std::max<int>(level, level_at(ux, uy));
     }
   }
   if (ux0 > 0 && uy0 > 0) {
     corner = 1;
-    level = std::max<int>(level, lvl[(size_t)(uy0 - 1) * seq.uw + ux0 - 1]);
+    level = std::max<int>(level, level_at(ux0 - 1, uy0 - 1));
   }
   level += 1;
   if (comp < 2)  // Cb and Cr share one map; Cr arrives right after Cb with identical geometry
@@ -225,8 +269,8 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
     it.flags |= IN_HAS_RESI;
     it.resi_off = off;
   }
-  intra.push_back(it);
-  intra_level.push_back((uint16_t)level);
+  ctu_items.push_back(it);
+  ctu_item_lvl.push_back((uint16_t)level);
 }
 
 void PackedPicture::intra_tus(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy, int zcu, int z, int size, int trdepth, int chroma) {
@@ -263,22 +307,22 @@ bool PackedPicture::finish(const hevcrecon_pic_params *p) {
       error = "bad reference list size";
       return false;
     }
-  // counting sort of the intra blocks by dependency level
-  int nlev = 0;
-  for (size_t i = 0; i < intra_level.size(); i++) nlev = std::max<int>(nlev, intra_level[i]);
-  std::vector<int32_t> count(nlev + 1, 0);  // levels start at 1
-  for (size_t i = 0; i < intra_level.size(); i++) count[intra_level[i]]++;
-  level_off.assign(nlev + 1, 0);  // level_off[l-1] = first item of level l; level_off[nlev] = total
+  // order the CTUs that hold intra blocks by wave
+  int nw = 0;
+  for (size_t i = 0; i < ictu_wave.size(); i++) nw = std::max<int>(nw, ictu_wave[i]);
+  std::vector<int32_t> count(nw + 1, 0);  // waves start at 1
+  for (size_t i = 0; i < ictu_wave.size(); i++) count[ictu_wave[i]]++;
+  wave_off.assign(nw + 1, 0);  // wave_off[w-1] = first CTU of wave w; wave_off[nw] = total
   int run = 0;
-  for (int l = 1; l <= nlev; l++) {
-    level_off[l - 1] = run;
-    run += count[l];
+  for (int w = 1; w <= nw; w++) {
+    wave_off[w - 1] = run;
+    run += count[w];
   }
-  level_off[nlev] = run;
-  std::vector<IntraItem> sorted(intra.size());
-  std::vector<int32_t> cursor(level_off.begin(), level_off.end());
-  for (size_t i = 0; i < intra.size(); i++) sorted[cursor[intra_level[i] - 1]++] = intra[i];
-  intra.swap(sorted);
+  wave_off[nw] = run;
+  std::vector<IntraCtu> sorted(ictu.size());
+  std::vector<int32_t> cursor(wave_off.begin(), wave_off.end());
+  for (size_t i = 0; i < ictu.size(); i++) sorted[cursor[ictu_wave[i] - 1]++] = ictu[i];
+  ictu.swap(sorted);
   finished = true;
   return true;
 }

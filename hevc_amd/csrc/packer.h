@@ -15,17 +15,24 @@ struct PackedPicture {
   std::vector<Part4> rec4;
   std::vector<TuItem> tu[4];
   std::vector<int16_t> coeff;
-  std::vector<IntraItem> intra;     // sorted by level after finish()
-  std::vector<int32_t> level_off;   // n_levels + 1
+  std::vector<IntraItem> intra;     // grouped by CTU, by local level inside a CTU
+  std::vector<IntraCtu> ictu;       // CTUs holding intra blocks, sorted by wave after finish()
+  std::vector<uint16_t> lvl_counts; // per CTU, per local level: number of blocks
+  std::vector<int32_t> wave_off;    // n_waves + 1 offsets into ictu
   std::vector<SaoCtu> sao;
+  int max_ref_idx[2];               // largest reference index used by an inter block, per list (-1: none)
+  bool inter_without_ref;           // an inter block with no reference at all (corrupt input)
   int64_t mc_ref_samples;           // luma+chroma samples predicted, counted once per reference used
   int next_ctu;
   bool finished;
   std::string error;
 
   // scratch
-  std::vector<uint16_t> intra_level;  // parallel to intra before sorting
-  std::vector<uint16_t> lvl_y, lvl_c; // per 4x4 unit: dependency level of the intra block covering it (0 = none)
+  std::vector<IntraItem> ctu_items;   // intra blocks of the CTU being added, in coding order
+  std::vector<uint16_t> ctu_item_lvl; // their local levels
+  std::vector<uint16_t> lvl_y, lvl_c; // per 4x4 unit: local level of the intra block covering it (0 = none)
+  std::vector<uint16_t> ctu_wave;     // per CTU: wave (0 = no intra blocks)
+  std::vector<uint16_t> ictu_wave;    // parallel to ictu before sorting
 
   void begin(const SeqInfo &s);
   bool add_ctu(int addr, const hevcrecon_ctu_syntax *ctu);

@@ -123,8 +123,9 @@ void hevcrecon_syntax_destroy(hevcrecon_syntax *syn);
 int hevcrecon_syntax_create_detached(const hevcrecon_seq_params *sp, hevcrecon_syntax **out);
 
 /* Counters of the packed picture: out[0..3] coded transform blocks of size 4/8/16/32, [4] coded coefficients,
- * [5] intra prediction blocks, [6] intra dependency levels, [7] reference samples read by inter prediction,
- * [8] 4x4 records, [9] 4x4 records that are intra, [10] finished flag. */
+ * [5] intra prediction blocks, [6] intra CTU waves, [7] reference samples read by inter prediction,
+ * [8] 4x4 records, [9] 4x4 records that are intra, [10] finished flag, [11] CTUs holding intra blocks,
+ * [12] sum over those CTUs of their local dependency levels. */
 int hevcrecon_syntax_stats(const hevcrecon_syntax *syn, int64_t out[16]);
 
 /* Start a new picture in `syn` (drops whatever it held).  Stands where TDecTop::xDecodeSlice
