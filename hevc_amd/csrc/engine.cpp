@@ -442,6 +442,25 @@ extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[16]
   for (size_t i = 0; i < k.rec4.size(); i++) intra4 += (k.rec4[i].flags & P4_INTRA) ? 1 : 0;
   out[9] = intra4;
   out[10] = k.finished ? 1 : 0;
+  // intra schedule: rounds of 4 blocks on the critical path (slowest CTU of every wave) and in total
+  if (k.finished && !k.wave_off.empty()) {
+    int64_t crit = 0, total = 0, crit_lvl = 0;
+    for (size_t w = 0; w + 1 < k.wave_off.size(); w++) {
+      int64_t worst = 0, worst_lvl = 0;
+      for (int i = k.wave_off[w]; i < k.wave_off[w + 1]; i++) {
+        int64_t r = 0;
+        for (int l = 0; l < k.ictu[i].n_lvl; l++) r += (k.lvl_counts[k.ictu[i].lvl_start + l] + 3) / 4;
+        total += r;
+        if (r > worst) worst = r;
+        if (k.ictu[i].n_lvl > worst_lvl) worst_lvl = k.ictu[i].n_lvl;
+      }
+      crit += worst;
+      crit_lvl += worst_lvl;
+    }
+    out[13] = crit;
+    out[14] = total;
+    out[15] = crit_lvl;
+  }
   return 0;
 }
 

@@ -437,6 +437,41 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
   }
 }
 
+// Wave-level helpers of k_intra.  hr_uniform: a value known to be equal in all lanes, moved to a scalar
+// register.  hr_wave_sync: orders LDS traffic between the lanes of ONE wave (a wave executes its LDS
+// instructions in order, so this only has to stop the compiler from moving accesses across it).
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ int hr_uniform(int v) { return v; }
+__device__ __forceinline__ unsigned hr_uniform(unsigned v) { return v; }
+__device__ __forceinline__ void hr_wave_sync() { emu::current_block().wave_barrier[emu::wave()].wait(); }
+__device__ __forceinline__ unsigned hr_brev(unsigned v) {
+  unsigned r = 0;
+  for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
+  return r;
+}
+#else
+__device__ __forceinline__ int hr_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned hr_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void hr_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ unsigned hr_brev(unsigned v) { return __brev(v); }
+#endif
+
+// Angular prediction of one sample from main-reference index i0 (>= 0 for positive angles) and fraction df.
+__device__ __forceinline__ int intra_ang_pos(const int *cn, int sgn, int i0, int df) {
+  const int a0 = cn[sgn * i0], a1 = cn[sgn * (i0 + 1)];
+  return df ? ((32 - df) * a0 + df * a1 + 16) >> 5 : a0;
+}
+__device__ __forceinline__ int intra_ang_neg(const int *cn, int sgn, int inv, int i0, int df) {
+  const int i1 = i0 + 1;
+  const int a0 = i0 >= 0 ? cn[sgn * i0] : cn[-sgn * ((128 - i0 * inv) >> 8)];
+  const int a1 = i1 >= 0 ? cn[sgn * i1] : cn[-sgn * ((128 - i1 * inv) >> 8)];
+  return df ? ((32 - df) * a0 + df * a1 + 16) >> 5 : a0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_intra: intra prediction + residual add.  One workgroup per CTU, one launch per CTU wave.
 // ------------------------------------------------------------------------------------------------
@@ -449,6 +484,7 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
 // Reference-sample array r[0..4n]: r[2n] is the corner, r[2n-1-j] the left column going down,
 // r[2n+1+i] the row above going right (TComPattern::initAdiPattern / fillReferenceSamples,
 // TLibCommon/TComPattern.cpp:213-602).  Availability comes per 4-luma-sample unit from the packer.
+#define IT_WAVES 4
 #define IT_YW 100 /* luma tile row: x = -1 .. 96 (97 used) */
 #define IT_CW 52  /* chroma tile row: x = -1 .. 48 (49 used) */
 #define IT_MAX_ITEMS 384
@@ -460,9 +496,9 @@ __global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, in
   __shared__ uint16_t tile_c[2][33 * IT_CW];
   __shared__ int16_t resi_y[64 * 64];
   __shared__ int16_t resi_c[2][32 * 32];
-  __shared__ IntraItem items_s[IT_MAX_ITEMS];
+  __shared__ __attribute__((aligned(16))) IntraItem items_s[IT_MAX_ITEMS];
   __shared__ uint16_t lvlc_s[IT_MAX_LEVELS];
-  __shared__ int raw_s[4][132], ref_s[4][132], flt_s[4][132];
+  __shared__ int ref_s[IT_WAVES][132], flt_s[IT_WAVES][132];
   const PicJob &J = jobs[blockIdx.y];
   if (wave_idx >= J.n_waves) return;
   const int first_ctu = J.wave_off[wave_idx];
@@ -556,89 +592,64 @@ __global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, in
   }
   __syncthreads();
 
-  int *raw = raw_s[wv], *ref = ref_s[wv], *flt = flt_s[wv];
+  int *ref = ref_s[wv], *flt = flt_s[wv];
   int base = 0;
   const int n_lvl = ci.n_lvl < IT_MAX_LEVELS ? ci.n_lvl : IT_MAX_LEVELS;
   for (int lvl = 0; lvl < n_lvl; lvl++) {
-    const int cnt = lvlc_s[lvl];
-    for (int r0 = 0; r0 < cnt; r0 += 4) {
+    const int cnt = hr_uniform((int)lvlc_s[lvl]);
+    for (int r0 = 0; r0 < cnt; r0 += IT_WAVES) {
       const int idx = r0 + wv;
-      const bool live = idx < cnt && base + idx < IT_MAX_ITEMS;
-      IntraItem it;
-      it.x = it.y = 0;
-      it.log2n = 2;
-      it.comp = 0;
-      it.mode = 1;
-      it.flags = 0;
-      it.avail_left = it.avail_above = 0;
-      it.resi_off = 0;
-      if (live) it = items_s[base + idx];
-      const int n = 1 << it.log2n, comp = it.comp;
-      const int sh = comp ? 1 : 0, us = 4 >> sh, nu = n / us;
+      if (idx >= cnt || base + idx >= IT_MAX_ITEMS) continue;  // wave-uniform: the rest of the body has no workgroup barrier
+      // The block's description is the same in every lane: keep it in scalar registers.
+      const unsigned *iw = (const unsigned *)&items_s[base + idx];
+      const unsigned w0 = hr_uniform(iw[0]), w1 = hr_uniform(iw[1]), w2 = hr_uniform(iw[2]);
+      const int x0 = w0 & 0xffff, y0 = w0 >> 16;
+      const int log2n = w1 & 255, comp = (w1 >> 8) & 255, mode = (w1 >> 16) & 255, flags = w1 >> 24;
+      const int n = 1 << log2n;
+      const int sh = comp ? 1 : 0, lus = 2 - sh, us = 1 << lus, nu = n >> lus;
       const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
       uint16_t *tile = comp ? tile_c[comp - 1] : tile_y;
       const int tw = comp ? IT_CW : IT_YW;
-      const int x0 = it.x, y0 = it.y, len = 4 * n + 1;
+      const int len = 4 * n + 1;
       // position of the block inside the tile (tile index 0 = sample -1 of the CTU)
       const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
 
       // availability of the 4*nu+1 units in scan order (bottom-left ... corner ... top-right)
-      unsigned long long m = 0;
-      for (int j = 0; j < 2 * nu; j++)
-        if ((it.avail_left >> j) & 1) m |= 1ull << (2 * nu - 1 - j);
-      if (it.flags & IN_CORNER) m |= 1ull << (2 * nu);
-      for (int i = 0; i < 2 * nu; i++)
-        if ((it.avail_above >> i) & 1) m |= 1ull << (2 * nu + 1 + i);
+      const unsigned long long m = (unsigned long long)(hr_brev(w2 & 0xffff) >> (32 - 2 * nu)) |
+                                   ((flags & IN_CORNER) ? 1ull << (2 * nu) : 0ull) |
+                                   ((unsigned long long)((w2 >> 16) & ((1u << (2 * nu)) - 1)) << (2 * nu + 1));
 
-      // 1. gather
-      for (int i = lane; i < len; i += 64) {
-        int u, sx, sy;  // unit, tile coordinates
-        if (i < 2 * n) {
-          u = i / us;
-          sx = tx0 - 1;
-          sy = ty0 + 2 * n - 1 - i;
-        } else if (i == 2 * n) {
-          u = 2 * nu;
-          sx = tx0 - 1;
-          sy = ty0 - 1;
-        } else {
-          u = 2 * nu + 1 + (i - 2 * n - 1) / us;
-          sx = tx0 + (i - 2 * n - 1);
-          sy = ty0 - 1;
-        }
-        int v = 0;
-        if (live && ((m >> u) & 1)) v = tile[sy * tw + sx];
-        raw[i] = v;
-      }
-      __syncthreads();
-      // 2. substitution of unavailable units (TLibCommon/TComPattern.cpp:424-435,546-588)
-      for (int i = lane; i < len; i += 64) {
-        const int u = i < 2 * n ? i / us : (i == 2 * n ? 2 * nu : 2 * nu + 1 + (i - 2 * n - 1) / us);
-        int v;
-        if ((m >> u) & 1) {
-          v = raw[i];
-        } else if (m == 0) {
-          v = 1 << (bd - 1);
-        } else {
-          const unsigned long long below = m & ((1ull << u) - 1);
-          int src;
-          if (below) {
-            const int ub = 63 - __clzll((long long)below);  // nearest available unit before this one: take its last sample
-            src = ub < 2 * nu ? ub * us + us - 1 : (ub == 2 * nu ? 2 * n : 2 * n + 1 + (ub - 2 * nu - 1) * us + us - 1);
-          } else {
-            const int ua = __ffsll((long long)m) - 1;  // none before: first sample of the first available unit
-            src = ua < 2 * nu ? ua * us : (ua == 2 * nu ? 2 * n : 2 * n + 1 + (ua - 2 * nu - 1) * us);
+      // 1. reference samples with unavailable units substituted (TLibCommon/TComPattern.cpp:424-435,546-588):
+      //    every lane works out which sample stands in for its position from the mask alone and reads it
+      //    straight from the tile.
+      if (m == 0) {
+        for (int i = lane; i < len; i += 64) ref[i] = 1 << (bd - 1);
+      } else {
+        const int ua = __ffsll((long long)m) - 1;  // first available unit: its first sample stands in for everything before it
+        const int first_src = ua < 2 * nu ? ua << lus : (ua == 2 * nu ? 2 * n : 2 * n + 1 + ((ua - 2 * nu - 1) << lus));
+        for (int i = lane; i < len; i += 64) {
+          const int u = i < 2 * n ? i >> lus : (i == 2 * n ? 2 * nu : 2 * nu + 1 + ((i - 2 * n - 1) >> lus));
+          int src = i;
+          if (!((m >> u) & 1)) {
+            const unsigned long long below = m & ((1ull << u) - 1);
+            if (below) {
+              const int ub = 63 - __clzll((long long)below);  // nearest available unit before this one: its last sample
+              src = ub < 2 * nu ? (ub << lus) + us - 1 : (ub == 2 * nu ? 2 * n : 2 * n + 1 + ((ub - 2 * nu - 1) << lus) + us - 1);
+            } else {
+              src = first_src;
+            }
           }
-          v = raw[src];
+          // sample index -> tile coordinates: left column bottom-up, corner, row above left to right
+          const int sx = src <= 2 * n ? tx0 - 1 : tx0 + (src - 2 * n - 1);
+          const int sy = src < 2 * n ? ty0 + 2 * n - 1 - src : ty0 - 1;
+          ref[i] = tile[sy * tw + sx];
         }
-        ref[i] = v;
       }
-      __syncthreads();
-      // 3. luma smoothing (TComPattern::getPredictorPtr :627-651 decides, :263-356 filters)
-      const int mode = it.mode;
+      hr_wave_sync();
+      // 2. luma smoothing (TComPattern::getPredictorPtr :627-651 decides, :263-356 filters)
       bool use_flt = false;
       if (comp == 0 && mode != 1) {
-        const int thr = it.log2n == 2 ? 10 : it.log2n == 3 ? 7 : it.log2n == 4 ? 1 : 0;
+        const int thr = log2n == 2 ? 10 : log2n == 3 ? 7 : log2n == 4 ? 1 : 0;
         use_flt = min(iabs(mode - 10), iabs(mode - 26)) > thr;
       }
       if (use_flt) {
@@ -664,79 +675,84 @@ __global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, in
           }
           flt[i] = v;
         }
+        hr_wave_sync();
       }
-      __syncthreads();
       const int *r = use_flt ? flt : ref;
       const int *cn = r + 2 * n;  // cn[0] corner, cn[-1-j] left[j], cn[1+i] above[i]
-      // DC value: wave reduction over the 2n neighbours (TLibCommon/TComPrediction.cpp:122-160)
-      int dcv = 0;
-      {
+      // 3. prediction (TLibCommon/TComPrediction.cpp:183-390,691-763) + residual + store
+      const bool edge = comp == 0 && n <= 16;
+      const int16_t *resi = comp ? resi_c[comp - 1] : resi_y;
+      const int rw = comp ? 32 : 64;
+      const bool has_resi = (flags & IN_HAS_RESI) != 0;
+      const int16_t *resi0 = resi + (ty0 - 1) * rw + tx0 - 1;
+      uint16_t *tile0 = tile + ty0 * tw + tx0;
+      const int npx = n * n;
+#define INTRA_STORE_LOOP(EXPR)                                            \
+  for (int p0 = 0; p0 < npx; p0 += 256) {                                 \
+    int vv[4];                                                            \
+    _Pragma("unroll") for (int k = 0; k < 4; k++) {                       \
+      const int p = p0 + k * 64 + lane;                                   \
+      const int py = p >> log2n, px = p & (n - 1);                        \
+      int v = 0;                                                          \
+      if (p < npx) {                                                      \
+        v = (EXPR);                                                       \
+        if (has_resi) v += resi0[py * rw + px];                           \
+      }                                                                   \
+      vv[k] = v;                                                          \
+    }                                                                     \
+    _Pragma("unroll") for (int k = 0; k < 4; k++) {                       \
+      const int p = p0 + k * 64 + lane;                                   \
+      const int py = p >> log2n, px = p & (n - 1);                        \
+      if (p < npx) tile0[py * tw + px] = (uint16_t)clip3i(0, maxv, vv[k]); \
+    }                                                                     \
+  }
+      if (mode == 0) {  // planar
+        const int tr = cn[1 + n], bl = cn[-1 - n];
+        INTRA_STORE_LOOP(((cn[-1 - py] << log2n) + n + (px + 1) * (tr - cn[-1 - py]) + (cn[1 + px] << log2n) + (py + 1) * (bl - cn[1 + px])) >> (log2n + 1))
+      } else if (mode == 1) {  // DC: wave reduction over the 2n neighbours (TLibCommon/TComPrediction.cpp:122-160)
         int part = 0;
         if (lane < 2 * n) part = lane < n ? cn[1 + lane] : cn[-1 - (lane - n)];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
-        dcv = (part + n) >> (it.log2n + 1);
-      }
-      // 4. prediction (TLibCommon/TComPrediction.cpp:183-390,691-763) + residual + store
-      const bool edge = comp == 0 && n <= 16;
-      const bool hor = mode >= 2 && mode < 18;
-      int angle = 0, inv = 0;
-      if (mode >= 2) {
+        const int dcv = (part + n) >> (log2n + 1);
+        if (edge) {
+          INTRA_STORE_LOOP((px == 0 && py == 0) ? (cn[1] + cn[-1] + 2 * dcv + 2) >> 2
+                           : py == 0            ? (cn[1 + px] + 3 * dcv + 2) >> 2
+                           : px == 0            ? (cn[-1 - py] + 3 * dcv + 2) >> 2
+                                                : dcv)
+        } else {
+          INTRA_STORE_LOOP(dcv)
+        }
+      } else {
+        // angular: vertical modes predict from the row above, horizontal modes are the same computation
+        // on the transposed block (main = left column): sgn flips the index direction
+        const bool hor = mode < 18;
         const int a = hor ? -(mode - 10) : mode - 26;
         const int aa = iabs(a);
         const int at = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
-        inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
-        angle = a < 0 ? -at : at;
-      }
-      // residual tile: same geometry as the sample tile without its border row / column
-      const int16_t *resi = comp ? resi_c[comp - 1] : resi_y;
-      const int rw = comp ? 32 : 64;
-      const bool has_resi = (it.flags & IN_HAS_RESI) != 0;
-      for (int p = lane; p < n * n; p += 64) {
-        const int py = p >> it.log2n, px = p & (n - 1);
-        int v;
-        if (mode == 0) {  // planar
-          const int l = cn[-1 - py], a = cn[1 + px];
-          const int hp = (l << it.log2n) + n + (px + 1) * (cn[1 + n] - l);
-          const int vp = (a << it.log2n) + (py + 1) * (cn[-1 - n] - a);
-          v = (hp + vp) >> (it.log2n + 1);
-        } else if (mode == 1) {  // DC
-          v = dcv;
+        const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
+        const int angle = a < 0 ? -at : at;
+        const int sgn = hor ? -1 : 1;  // MAIN(i) = cn[sgn * i], SIDE(i) = cn[-sgn * i]
+#define KK (hor ? px : py) /* index along the prediction direction */
+#define EE (hor ? py : px) /* index across it */
+        if (angle == 0) {
           if (edge) {
-            if (px == 0 && py == 0)
-              v = (cn[1] + cn[-1] + 2 * dcv + 2) >> 2;
-            else if (py == 0)
-              v = (cn[1 + px] + 3 * dcv + 2) >> 2;
-            else if (px == 0)
-              v = (cn[-1 - py] + 3 * dcv + 2) >> 2;
-          }
-        } else {
-          // angular: vertical modes predict from the row above, horizontal modes are the same computation
-          // on the transposed block (main = left column)
-          const int k = hor ? px : py;  // index along the prediction direction
-          const int e = hor ? py : px;  // index across it
-#define MAIN(i) (hor ? cn[-(i)] : cn[(i)])
-#define SIDE(i) (hor ? cn[(i)] : cn[-(i)])
-          if (angle == 0) {
-            v = MAIN(e + 1);
-            if (edge && e == 0) v = clip3i(0, maxv, v + ((SIDE(k + 1) - SIDE(0)) >> 1));
+            const int side0 = cn[0];
+            INTRA_STORE_LOOP(EE == 0 ? clip3i(0, maxv, cn[sgn] + ((cn[-sgn * (KK + 1)] - side0) >> 1)) : cn[sgn * (EE + 1)])
           } else {
-            const int pos = (k + 1) * angle;
-            const int di = pos >> 5, df = pos & 31;
-            const int i0 = e + di + 1, i1 = i0 + 1;
-            // negative indices address the side reference projected onto the main one
-            const int a0 = i0 >= 0 ? MAIN(i0) : SIDE((128 - i0 * inv) >> 8);
-            const int a1 = i1 >= 0 ? MAIN(i1) : SIDE((128 - i1 * inv) >> 8);
-            v = df ? ((32 - df) * a0 + df * a1 + 16) >> 5 : a0;
+            INTRA_STORE_LOOP(cn[sgn * (EE + 1)])
           }
-#undef MAIN
-#undef SIDE
+        } else if (angle > 0) {
+          INTRA_STORE_LOOP(intra_ang_pos(cn, sgn, EE + 1 + (((KK + 1) * angle) >> 5), ((KK + 1) * angle) & 31))
+        } else {
+          // negative indices address the side reference projected onto the main one
+          INTRA_STORE_LOOP(intra_ang_neg(cn, sgn, inv, EE + 1 + (((KK + 1) * angle) >> 5), ((KK + 1) * angle) & 31))
         }
-        if (live) {
-          if (has_resi) v += resi[(ty0 - 1 + py) * rw + tx0 - 1 + px];
-          tile[(ty0 + py) * tw + tx0 + px] = (uint16_t)clip3i(0, maxv, v);
-        }
+#undef KK
+#undef EE
       }
+#undef INTRA_STORE_LOOP
+      hr_wave_sync();  // the wave's next block reuses ref / flt
     }
     base += cnt;
     __syncthreads();  // the next level reads what this one wrote into the tile
