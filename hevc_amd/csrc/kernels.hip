@@ -174,40 +174,53 @@ __device__ __forceinline__ void interp_u8(const uint8_t *ref, int stride, int pw
   constexpr int HALF = NT / 2 - 1;
   constexpr int NPIX = BW + NT - 1;
   constexpr int NW = (NPIX + 3) / 4;
+  constexpr int ROWS = BH + NT - 1;
   const int xs = x0 - HALF, ys = y0 - HALF;
-  const bool inside = xs >= 0 && xs + NPIX - 1 < pw && ys >= 0 && ys + BH + NT - 2 < ph;
+  const bool inside = xs >= 0 && xs + NPIX - 1 < pw && ys >= 0 && ys + ROWS - 1 < ph;
   const int a = xs & ~3, sh = xs & 3;
+  // All rows are fetched before any is used, so the block costs one trip to memory instead of one per row.
+  // With a zero vertical fraction only the BH middle rows matter: the others re-read a middle row (same
+  // cache line, no extra traffic) and are skipped below.
+  unsigned w[ROWS][NW];
+  if (inside) {
+    unsigned d[ROWS][NW + 1];
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      const int rr = v_identity ? clip3i(HALF, HALF + BH - 1, r) : r;
+      const unsigned *rp = (const unsigned *)(ref + (size_t)(ys + rr) * stride + a);
+#pragma unroll
+      for (int k = 0; k <= NW; k++) d[r][k] = rp[k];
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; r++)
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[r][k] = hr_alignbyte(d[r][k + 1], d[r][k], sh) ^ 0x80808080u;
+  } else {
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      const uint8_t *row = ref + (size_t)clip3i(0, ph - 1, ys + r) * stride;
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[r][k] = 0;
+#pragma unroll
+      for (int i = 0; i < NPIX; i++) w[r][i >> 2] |= (unsigned)row[clip3i(0, pw - 1, xs + i)] << (8 * (i & 3));
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[r][k] ^= 0x80808080u;
+    }
+  }
   int acc[BH][BW];
 #pragma unroll
   for (int j = 0; j < BH; j++)
 #pragma unroll
     for (int i = 0; i < BW; i++) acc[j][i] = 0;
 #pragma unroll
-  for (int r = 0; r < BH + NT - 1; r++) {
+  for (int r = 0; r < ROWS; r++) {
     if (v_identity && (r < HALF || r > HALF + BH - 1)) continue;
-    unsigned w[NW];
-    if (inside) {
-      const unsigned *rp = (const unsigned *)(ref + (size_t)(ys + r) * stride + a);
-      unsigned d[NW + 1];
-#pragma unroll
-      for (int k = 0; k <= NW; k++) d[k] = rp[k];
-#pragma unroll
-      for (int k = 0; k < NW; k++) w[k] = hr_alignbyte(d[k + 1], d[k], sh);
-    } else {
-      const uint8_t *row = ref + (size_t)clip3i(0, ph - 1, ys + r) * stride;
-#pragma unroll
-      for (int k = 0; k < NW; k++) w[k] = 0;
-#pragma unroll
-      for (int i = 0; i < NPIX; i++) w[i >> 2] |= (unsigned)row[clip3i(0, pw - 1, xs + i)] << (8 * (i & 3));
-    }
-#pragma unroll
-    for (int k = 0; k < NW; k++) w[k] ^= 0x80808080u;
 #pragma unroll
     for (int i = 0; i < BW; i++) {
-      const unsigned lo = i ? hr_alignbyte(w[1], w[0], i) : w[0];
+      const unsigned lo = i ? hr_alignbyte(w[r][1], w[r][0], i) : w[r][0];
       int h = hr_sdot4(lo, tlo, 0);
       if (NT == 8) {
-        const unsigned hi = i ? hr_alignbyte(w[NW - 1], w[1], i) : w[1];
+        const unsigned hi = i ? hr_alignbyte(w[r][NW - 1], w[r][1], i) : w[r][1];
         h = hr_sdot4(hi, thi, h);
       }
 #pragma unroll
@@ -226,7 +239,12 @@ __device__ __forceinline__ void interp_u8(const uint8_t *ref, int stride, int pw
 template <typename pel_t>
 __global__ __launch_bounds__(256) void k_inter(const PicJob *jobs, SeqInfo s) {
   const PicJob &J = jobs[blockIdx.y];
-  const int cx = blockIdx.x % s.ctus_w, cy = blockIdx.x / s.ctus_w;
+  // Workgroups go to the 8 XCDs round-robin; give each XCD a contiguous run of CTUs (in raster order) so that
+  // neighbouring CTUs, whose reference windows overlap and share cache lines, meet in the same L2.
+  const int nctu = s.ctus_w * s.ctus_h, per_xcd = (nctu + 7) >> 3;
+  const int ctu = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (ctu >= nctu) return;
+  const int cx = ctu % s.ctus_w, cy = ctu / s.ctus_w;
   const int ux = cx * 16 + (threadIdx.x & 15), uy = cy * 16 + (threadIdx.x >> 4);
   if (J.slice_type == 2 || ux >= s.uw || uy >= s.uh) return;
   const Part4 p = J.rec4[(size_t)uy * s.uw + ux];
@@ -1049,7 +1067,8 @@ template <typename pel_t>
 static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t st, int arg, int arg2) {
   switch (kind) {
     case K_INTER:
-      LAUNCH(k_inter<pel_t>, dim3(s.ctus_w * s.ctus_h, n), dim3(256), st, jobs, s);
+      // grid.x a multiple of 8, so that blockIdx.x & 7 is the XCD for every picture of the batch
+      LAUNCH(k_inter<pel_t>, dim3((s.ctus_w * s.ctus_h + 7) / 8 * 8, n), dim3(256), st, jobs, s);
       break;
     case K_TRANSFORM: {
       // arg = log2 size, arg2 = max number of blocks of that size over the batch
