@@ -1,6 +1,6 @@
 // common.h — data layout shared by the host packer and the gfx950 kernels.
 //
-// Everything a picture needs lives in HBM in five flat arrays, written once by the host packer
+// Everything a picture needs lives in HBM in a few flat arrays, written once by the host packer
 // (packer.cpp) and read by every kernel:
 //   * Part4   rec4[(H/4)*(W/4)]  one 16-byte record per 4x4 luma block, RASTER order over the picture
 //                                (the reference keeps these per CTU in z-order: TLibCommon/TComDataCU.h:122-204)
@@ -10,6 +10,7 @@
 //                                dependency level; IntraCtu ictu[...] one entry per CTU that holds intra blocks,
 //                                sorted by CTU wave (a CTU's wave is one more than the highest wave among its left,
 //                                above-left, above and above-right neighbours that hold intra blocks)
+//   * McTile  mc_tile[...] / McBlk mc_blk[...]  32x32 regions with uniform / mixed motion
 //   * SaoCtu  sao[nCtu*3]        SAO parameters per CTU and component
 // Sample planes are uint8 for 8-bit sequences and uint16 otherwise, with no margin: kernels clamp
 // reference coordinates instead of reading the reference's 80-sample replicated border.
@@ -55,6 +56,19 @@ struct TuItem {
   int8_t qp;         /* luma QP of the coding unit */
   uint8_t pad;
   uint32_t coeff_off; /* index of the block's first coefficient in coeff[] (and of its residual in resi[]) */
+};
+
+// Motion compensation work lists.  The picture is cut into 32x32 luma regions; a region whose inter blocks all
+// carry the same (clipped) motion goes to mc_tile and is predicted as one block by a whole workgroup, the
+// others go to mc_blk and are predicted 4x4 unit by 4x4 unit from the motion records.
+struct McTile {
+  uint16_t x, y;     /* luma position of the region */
+  int16_t mv[2][2];  /* [list][hor, ver], quarter luma samples, already clipped */
+  int8_t ref[2];     /* reference index per list, -1: list not used (identical-motion shortcut applied) */
+  uint8_t pad[2];
+};
+struct McBlk {
+  uint16_t x, y; /* luma position of the region */
 };
 
 #define IN_CORNER 0x01
@@ -103,6 +117,9 @@ struct PicJob {
   const void *ref[2][HR_MAX_REFS][3]; /* reference pictures (final planes) */
   int32_t ref_poc[2][HR_MAX_REFS];
   const Part4 *rec4;
+  const McTile *mc_tile;
+  const McBlk *mc_blk;
+  int32_t n_mc_tile, n_mc_blk;
   const TuItem *tu[4];
   int32_t n_tu[4];
   const int16_t *coeff;

@@ -236,17 +236,9 @@ __device__ __forceinline__ void interp_u8(const uint8_t *ref, int stride, int pw
     for (int i = 0; i < BW; i++) out[j][i] = acc[j][i] >> 6;
 }
 
+// Motion-compensated prediction of one 4x4 luma unit (and its 2x2 chroma units) straight from its motion record.
 template <typename pel_t>
-__global__ __launch_bounds__(256) void k_inter(const PicJob *jobs, SeqInfo s) {
-  const PicJob &J = jobs[blockIdx.y];
-  // Workgroups go to the 8 XCDs round-robin; give each XCD a contiguous run of CTUs (in raster order) so that
-  // neighbouring CTUs, whose reference windows overlap and share cache lines, meet in the same L2.
-  const int nctu = s.ctus_w * s.ctus_h, per_xcd = (nctu + 7) >> 3;
-  const int ctu = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (ctu >= nctu) return;
-  const int cx = ctu % s.ctus_w, cy = ctu / s.ctus_w;
-  const int ux = cx * 16 + (threadIdx.x & 15), uy = cy * 16 + (threadIdx.x >> 4);
-  if (J.slice_type == 2 || ux >= s.uw || uy >= s.uh) return;
+__device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, int ux, int uy) {
   const Part4 p = J.rec4[(size_t)uy * s.uw + ux];
   if (p.flags & P4_INTRA) return;
   const int x = ux * 4, y = uy * 4;
@@ -343,6 +335,212 @@ __global__ __launch_bounds__(256) void k_inter(const PicJob *jobs, SeqInfo s) {
         dst += s.stride_c;
       }
     }
+  }
+}
+
+// k_inter_blk: regions with mixed motion.  One wave per 32x32 region, one lane per 4x4 unit.
+template <typename pel_t>
+__global__ __launch_bounds__(256) void k_inter_blk(const PicJob *jobs, SeqInfo s) {
+  const PicJob &J = jobs[blockIdx.y];
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= J.n_mc_blk) return;
+  const McBlk b = J.mc_blk[r];
+  const int lane = threadIdx.x & 63;
+  const int ux = (b.x >> 2) + (lane & 7), uy = (b.y >> 2) + (lane >> 3);
+  if (ux >= s.uw || uy >= s.uh) return;
+  inter_unit<pel_t>(J, s, ux, uy);
+}
+
+// ---- k_inter_tile: regions with uniform motion, 8-bit pictures -----------------------------------------
+// One workgroup predicts a 32x32 luma region and its two 16x16 chroma regions as single blocks.
+//   phase H  every lane filters two rows x eight outputs horizontally, straight from the reference picture
+//            (one unaligned 16-byte load per row: 8 lanes cover a window row contiguously, so the loads
+//            coalesce), and stores the 16-bit intermediates of the two rows packed in one dword, P[pair][x];
+//   phase V  one lane per column and four rows: the vertical filter as 2-way 16-bit dot products over the
+//            packed row pairs (odd rows use the tap pairs shifted by one), both lists accumulated in
+//            registers, then the uni- or bi-prediction rounding; the bytes go to an LDS tile;
+//   store    the tile is written out as dwords, 32 (16) bytes per row.
+// Arithmetic as in interp_u8: samples biased by 128 so the horizontal sums ARE the reference's 14-bit
+// intermediates; TComInterpolationFilter.cpp:165-246, TComPrediction.cpp:413-507, TComYuv.cpp:520-584.
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ int hr_sdot2(unsigned a, unsigned b, int c) {
+  return c + (int)(int16_t)(a & 0xffff) * (int)(int16_t)(b & 0xffff) + (int)(int16_t)(a >> 16) * (int)(int16_t)(b >> 16);
+}
+#else
+typedef short hr_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int hr_sdot2(unsigned a, unsigned b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(hr_short2, a), __builtin_bit_cast(hr_short2, b), c, false);
+}
+#endif
+__device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+
+struct __attribute__((packed)) HrBytes16 { unsigned v[4]; };
+struct __attribute__((packed)) HrBytes12 { unsigned v[3]; };
+
+// NB bytes of row `row` starting at sample x0 (clamped into the row when !fast), as NB/4 dwords
+template <int ND>
+__device__ __forceinline__ void tile_row_load(const uint8_t *row, int x0, int pw, bool fast, unsigned w[ND]) {
+  if (fast) {
+    if constexpr (ND == 4) {
+      const HrBytes16 q = *(const HrBytes16 *)(row + x0);
+#pragma unroll
+      for (int k = 0; k < 4; k++) w[k] = q.v[k];
+    } else {
+      const HrBytes12 q = *(const HrBytes12 *)(row + x0);
+#pragma unroll
+      for (int k = 0; k < 3; k++) w[k] = q.v[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < ND; k++) w[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 4 * ND; i++) w[i >> 2] |= (unsigned)row[clip3i(0, pw - 1, x0 + i)] << (8 * (i & 3));
+  }
+}
+
+#define MT_PY (20 * 32) /* luma row pairs x columns */
+#define MT_PC (10 * 16)
+
+__global__ __launch_bounds__(256, 8) void k_inter_tile(const PicJob *jobs, SeqInfo s) {
+  __shared__ unsigned P_y[2][MT_PY];
+  __shared__ unsigned P_c[2][2][MT_PC];
+  __shared__ unsigned out_y[32 * 8];
+  __shared__ unsigned out_c[2][16 * 4];
+  const PicJob &J = jobs[blockIdx.y];
+  // XCD-contiguous order: workgroups go to the 8 XCDs round-robin; consecutive regions share cache lines
+  const int n = J.n_mc_tile, per_xcd = (n + 7) >> 3;
+  const int idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || idx >= n) return;
+  const McTile t = J.mc_tile[idx];
+  const int tid = threadIdx.x;
+  const int rx = t.x, ry = t.y;
+
+  // ---- phase H ----
+  if (tid < 160) {
+    const int l = tid >= 80 ? 1 : 0, k = tid - 80 * l;
+    if (t.ref[l] >= 0) {
+      const int p = k >> 2, o = k & 3;
+      const uint8_t *ref = (const uint8_t *)J.ref[l][t.ref[l]][0];
+      const int mvx = t.mv[l][0], mvy = t.mv[l][1];
+      int tx[8];
+      luma_taps(mvx & 3, tx);
+      const unsigned tlo = pack4(tx[0], tx[1], tx[2], tx[3]), thi = pack4(tx[4], tx[5], tx[6], tx[7]);
+      const int wx0 = rx + (mvx >> 2) - 3, wy0 = ry + (mvy >> 2) - 3;
+      const bool fast = wx0 >= 0 && wx0 + 38 < s.w;
+      int h[2][8];
+#pragma unroll
+      for (int rr = 0; rr < 2; rr++) {
+        const int r = min(2 * p + rr, 38);
+        const uint8_t *row = ref + (size_t)clip3i(0, s.h - 1, wy0 + r) * s.stride_y;
+        unsigned w[4];
+        tile_row_load<4>(row, wx0 + 8 * o, s.w, fast, w);
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[q] ^= 0x80808080u;
+        unsigned a[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) a[i] = (i & 3) ? hr_alignbyte(w[(i >> 2) + 1], w[i >> 2], i & 3) : w[i >> 2];
+#pragma unroll
+        for (int i = 0; i < 8; i++) h[rr][i] = hr_sdot4(a[i + 4], thi, hr_sdot4(a[i], tlo, 0));
+      }
+      unsigned *dst = &P_y[l][p * 32 + 8 * o];
+#pragma unroll
+      for (int i = 0; i < 8; i++) dst[i] = pack16(h[0][i], h[1][i]);
+    }
+  } else if (tid < 240) {
+    const int l = tid >= 200 ? 1 : 0, k = tid - 160 - 40 * l;
+    if (t.ref[l] >= 0) {
+      const int comp = k >= 20 ? 1 : 0, kk = k - 20 * comp;
+      const int p = kk >> 1, o = kk & 1;
+      const uint8_t *ref = (const uint8_t *)J.ref[l][t.ref[l]][1 + comp];
+      const int mvx = t.mv[l][0], mvy = t.mv[l][1];
+      int tx[4];
+      chroma_taps(mvx & 7, tx);
+      const unsigned tc = pack4(tx[0], tx[1], tx[2], tx[3]);
+      const int wx0 = (rx >> 1) + (mvx >> 3) - 1, wy0 = (ry >> 1) + (mvy >> 3) - 1;
+      const bool fast = wx0 >= 0 && wx0 + 18 < s.cw;
+      int h[2][8];
+#pragma unroll
+      for (int rr = 0; rr < 2; rr++) {
+        const int r = min(2 * p + rr, 18);
+        const uint8_t *row = ref + (size_t)clip3i(0, s.ch - 1, wy0 + r) * s.stride_c;
+        unsigned w[3];
+        tile_row_load<3>(row, wx0 + 8 * o, s.cw, fast, w);
+#pragma unroll
+        for (int q = 0; q < 3; q++) w[q] ^= 0x80808080u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const unsigned a = (i & 3) ? hr_alignbyte(w[(i >> 2) + 1], w[i >> 2], i & 3) : w[i >> 2];
+          h[rr][i] = hr_sdot4(a, tc, 0);
+        }
+      }
+      unsigned *dst = &P_c[l][comp][p * 16 + 8 * o];
+#pragma unroll
+      for (int i = 0; i < 8; i++) dst[i] = pack16(h[0][i], h[1][i]);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase V ----
+  const bool bi = t.ref[0] >= 0 && t.ref[1] >= 0;
+  // 8-bit samples: uni (v + 8192 + 32) >> 6, bi (v0 + v1 + 16384 + 64) >> 7
+  const int fsh = bi ? 7 : 6, foff = bi ? 16384 + 64 : 8192 + 32;
+  {
+    const int x = tid & 31, g = tid >> 5;
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      if (t.ref[l] < 0) continue;
+      int ty[8];
+      luma_taps(t.mv[l][1] & 3, ty);
+      const unsigned e0 = pack16(ty[0], ty[1]), e1 = pack16(ty[2], ty[3]), e2 = pack16(ty[4], ty[5]), e3 = pack16(ty[6], ty[7]);
+      const unsigned o0 = pack16(0, ty[0]), o1 = pack16(ty[1], ty[2]), o2 = pack16(ty[3], ty[4]), o3 = pack16(ty[5], ty[6]),
+                     o4 = pack16(ty[7], 0);
+      unsigned q[6];
+#pragma unroll
+      for (int i = 0; i < 6; i++) q[i] = P_y[l][(2 * g + i) * 32 + x];
+      acc[0] += hr_sdot2(q[3], e3, hr_sdot2(q[2], e2, hr_sdot2(q[1], e1, hr_sdot2(q[0], e0, 0)))) >> 6;
+      acc[1] += hr_sdot2(q[4], o4, hr_sdot2(q[3], o3, hr_sdot2(q[2], o2, hr_sdot2(q[1], o1, hr_sdot2(q[0], o0, 0))))) >> 6;
+      acc[2] += hr_sdot2(q[4], e3, hr_sdot2(q[3], e2, hr_sdot2(q[2], e1, hr_sdot2(q[1], e0, 0)))) >> 6;
+      acc[3] += hr_sdot2(q[5], o4, hr_sdot2(q[4], o3, hr_sdot2(q[3], o2, hr_sdot2(q[2], o1, hr_sdot2(q[1], o0, 0))))) >> 6;
+    }
+    uint8_t *ob = (uint8_t *)out_y;
+#pragma unroll
+    for (int j = 0; j < 4; j++) ob[(4 * g + j) * 32 + x] = (uint8_t)clip3i(0, 255, (acc[j] + foff) >> fsh);
+  }
+  if (tid < 128) {
+    const int comp = tid >> 6, x = tid & 15, g = (tid >> 4) & 3;
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      if (t.ref[l] < 0) continue;
+      int ty[4];
+      chroma_taps(t.mv[l][1] & 7, ty);
+      const unsigned e0 = pack16(ty[0], ty[1]), e1 = pack16(ty[2], ty[3]);
+      const unsigned o0 = pack16(0, ty[0]), o1 = pack16(ty[1], ty[2]), o2 = pack16(ty[3], 0);
+      unsigned q[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) q[i] = P_c[l][comp][(2 * g + i) * 16 + x];
+      acc[0] += hr_sdot2(q[1], e1, hr_sdot2(q[0], e0, 0)) >> 6;
+      acc[1] += hr_sdot2(q[2], o2, hr_sdot2(q[1], o1, hr_sdot2(q[0], o0, 0))) >> 6;
+      acc[2] += hr_sdot2(q[2], e1, hr_sdot2(q[1], e0, 0)) >> 6;
+      acc[3] += hr_sdot2(q[3], o2, hr_sdot2(q[2], o1, hr_sdot2(q[1], o0, 0))) >> 6;
+    }
+    uint8_t *ob = (uint8_t *)out_c[comp];
+#pragma unroll
+    for (int j = 0; j < 4; j++) ob[(4 * g + j) * 16 + x] = (uint8_t)clip3i(0, 255, (acc[j] + foff) >> fsh);
+  }
+  __syncthreads();
+
+  // ---- store ----
+  {
+    const int row = tid >> 3, dw = tid & 7;
+    if (ry + row < s.h && rx + 4 * dw < s.w)
+      *(unsigned *)((uint8_t *)J.rec[0] + (size_t)(ry + row) * s.stride_y + rx + 4 * dw) = out_y[row * 8 + dw];
+  }
+  if (tid < 128) {
+    const int comp = tid >> 6, row = (tid >> 2) & 15, dw = tid & 3;
+    const int cx = (rx >> 1) + 4 * dw, cy = (ry >> 1) + row;
+    if (cy < s.ch && cx < s.cw) *(unsigned *)((uint8_t *)J.rec[1 + comp] + (size_t)cy * s.stride_c + cx) = out_c[comp][row * 4 + dw];
   }
 }
 
@@ -1067,8 +1265,11 @@ template <typename pel_t>
 static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t st, int arg, int arg2) {
   switch (kind) {
     case K_INTER:
-      // grid.x a multiple of 8, so that blockIdx.x & 7 is the XCD for every picture of the batch
-      LAUNCH(k_inter<pel_t>, dim3((s.ctus_w * s.ctus_h + 7) / 8 * 8, n), dim3(256), st, jobs, s);
+      // arg = max number of uniform regions over the batch, arg2 = max number of mixed regions.
+      // Tile grid.x is a multiple of 8, so that blockIdx.x & 7 is the XCD for every picture of the batch.
+      if constexpr (sizeof(pel_t) == 1)
+        if (arg > 0) LAUNCH(k_inter_tile, dim3((arg + 7) / 8 * 8, n), dim3(256), st, jobs, s);
+      if (arg2 > 0) LAUNCH(k_inter_blk<pel_t>, dim3((arg2 + 3) / 4, n), dim3(256), st, jobs, s);
       break;
     case K_TRANSFORM: {
       // arg = log2 size, arg2 = max number of blocks of that size over the batch

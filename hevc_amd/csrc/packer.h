@@ -20,6 +20,8 @@ struct PackedPicture {
   std::vector<uint16_t> lvl_counts; // per CTU, per local level: number of blocks
   std::vector<int32_t> wave_off;    // n_waves + 1 offsets into ictu
   std::vector<SaoCtu> sao;
+  std::vector<McTile> mc_tile;      // filled by finish(): regions predicted as one block
+  std::vector<McBlk> mc_blk;        // filled by finish(): regions predicted unit by unit
   int max_ref_idx[2];               // largest reference index used by an inter block, per list (-1: none)
   bool inter_without_ref;           // an inter block with no reference at all (corrupt input)
   int64_t mc_ref_samples;           // luma+chroma samples predicted, counted once per reference used
@@ -46,6 +48,7 @@ struct PackedPicture {
   void emit_tu(const hevcrecon_ctu_syntax *ctu, int comp, int z, int zcu, int x, int y, int log2n, int flags, uint32_t *off_out);
   void emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z, int zcu, int x, int y, int log2n, int mode);
   int coding_order(int ux, int uy) const;
+  void build_mc_lists();
 };
 
 #endif
