@@ -10,7 +10,7 @@
 //                                dependency level; IntraCtu ictu[...] one entry per CTU that holds intra blocks,
 //                                sorted by CTU wave (a CTU's wave is one more than the highest wave among its left,
 //                                above-left, above and above-right neighbours that hold intra blocks)
-//   * McTile  mc_tile[...] / McBlk mc_blk[...]  32x32 regions with uniform / mixed motion
+//   * McTile  mc_tile[3][...] / McBlk mc_blk[...]  regions with uniform / mixed motion
 //   * SaoCtu  sao[nCtu*3]        SAO parameters per CTU and component
 // Sample planes are uint8 for 8-bit sequences and uint16 otherwise, with no margin: kernels clamp
 // reference coordinates instead of reading the reference's 80-sample replicated border.
@@ -58,9 +58,9 @@ struct TuItem {
   uint32_t coeff_off; /* index of the block's first coefficient in coeff[] (and of its residual in resi[]) */
 };
 
-// Motion compensation work lists.  The picture is cut into 32x32 luma regions; a region whose inter blocks all
-// carry the same (clipped) motion goes to mc_tile and is predicted as one block by a whole workgroup, the
-// others go to mc_blk and are predicted 4x4 unit by 4x4 unit from the motion records.
+// Motion compensation work lists.  Square luma regions (a whole CTU, else its 32x32 quadrants, else their 16x16
+// quadrants) whose units all carry the same (clipped) motion go to mc_tile[0..2] and are predicted as one
+// block; the 16x16 regions left over go to mc_blk and are predicted 4x4 unit by 4x4 unit from the motion records.
 struct McTile {
   uint16_t x, y;     /* luma position of the region */
   int16_t mv[2][2];  /* [list][hor, ver], quarter luma samples, already clipped */
@@ -117,9 +117,9 @@ struct PicJob {
   const void *ref[2][HR_MAX_REFS][3]; /* reference pictures (final planes) */
   int32_t ref_poc[2][HR_MAX_REFS];
   const Part4 *rec4;
-  const McTile *mc_tile;
+  const McTile *mc_tile[3]; /* 64x64, 32x32, 16x16 */
   const McBlk *mc_blk;
-  int32_t n_mc_tile, n_mc_blk;
+  int32_t n_mc_tile[3], n_mc_blk;
   const TuItem *tu[4];
   int32_t n_tu[4];
   const int16_t *coeff;

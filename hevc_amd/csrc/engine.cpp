@@ -75,7 +75,7 @@ struct hevcrecon_syntax {
   size_t dev_cap = 0;
   char *host = nullptr;  // pinned staging
   size_t host_cap = 0;
-  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_mct = 0, off_mcb = 0;
+  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_mct[3] = {0, 0, 0}, off_mcb = 0;
   bool uploaded = false;
   std::string err;
 };
@@ -394,7 +394,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   s->off_lvlc = place(k.lvl_counts.size() * sizeof(uint16_t));
   s->off_wave = place(k.wave_off.size() * sizeof(int32_t));
   s->off_sao = place(k.sao.size() * sizeof(SaoCtu));
-  s->off_mct = place(k.mc_tile.size() * sizeof(McTile));
+  for (int i = 0; i < 3; i++) s->off_mct[i] = place(k.mc_tile[i].size() * sizeof(McTile));
   s->off_mcb = place(k.mc_blk.size() * sizeof(McBlk));
   const size_t upload_bytes = off;
   const size_t total = off;
@@ -423,7 +423,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   std::memcpy(s->host + s->off_lvlc, k.lvl_counts.data(), k.lvl_counts.size() * sizeof(uint16_t));
   std::memcpy(s->host + s->off_wave, k.wave_off.data(), k.wave_off.size() * sizeof(int32_t));
   std::memcpy(s->host + s->off_sao, k.sao.data(), k.sao.size() * sizeof(SaoCtu));
-  std::memcpy(s->host + s->off_mct, k.mc_tile.data(), k.mc_tile.size() * sizeof(McTile));
+  for (int i = 0; i < 3; i++) std::memcpy(s->host + s->off_mct[i], k.mc_tile[i].data(), k.mc_tile[i].size() * sizeof(McTile));
   std::memcpy(s->host + s->off_mcb, k.mc_blk.data(), k.mc_blk.size() * sizeof(McBlk));
   HIPCHK(c, hipMemcpyAsync(s->dev, s->host, upload_bytes, hipMemcpyHostToDevice, c->stream));
   s->uploaded = true;
@@ -519,7 +519,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
   if (c->ring_used[slot]) HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
   PicJob *jh = c->jobs_host + (size_t)slot * HR_MAX_BATCH;
   PicJob *jd = c->jobs_dev + (size_t)slot * HR_MAX_BATCH;
-  int max_tu[4] = {0, 0, 0, 0}, max_levels = 0, max_mct = 0, max_mcb = 0;
+  int max_tu[4] = {0, 0, 0, 0}, max_levels = 0, max_mct[3] = {0, 0, 0}, max_mcb = 0;
   bool any_deblock = false, any_sao = false;
   for (int i = 0; i < n; i++) {
     hevcrecon_syntax *y = syn[i];
@@ -542,11 +542,13 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
         j.ref_poc[l][r] = k.pp.ref_poc[l][r];
       }
     j.rec4 = (const Part4 *)(y->dev + y->off_rec4);
-    j.mc_tile = (const McTile *)(y->dev + y->off_mct);
+    for (int t = 0; t < 3; t++) {
+      j.mc_tile[t] = (const McTile *)(y->dev + y->off_mct[t]);
+      j.n_mc_tile[t] = (int)k.mc_tile[t].size();
+      max_mct[t] = std::max(max_mct[t], j.n_mc_tile[t]);
+    }
     j.mc_blk = (const McBlk *)(y->dev + y->off_mcb);
-    j.n_mc_tile = (int)k.mc_tile.size();
     j.n_mc_blk = (int)k.mc_blk.size();
-    max_mct = std::max(max_mct, j.n_mc_tile);
     max_mcb = std::max(max_mcb, j.n_mc_blk);
     for (int t = 0; t < 4; t++) {
       j.tu[t] = (const TuItem *)(y->dev + y->off_tu[t]);
@@ -579,9 +581,12 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
   HIPCHK(c, hipEventRecord(c->ring_ev[slot], c->stream));
   c->ring_used[slot] = true;
   // ---- launches ----
-  if (max_mct > 0 || max_mcb > 0) {
-    Timed t(c, K_INTER, (max_mct > 0) + (max_mcb > 0));
-    hr_launch(K_INTER, jd, n, s, c->stream, max_mct, max_mcb);
+  if (max_mct[0] > 0 || max_mct[1] > 0 || max_mct[2] > 0 || max_mcb > 0) {
+    // arg = 0..2: uniform regions of 64, 32, 16 samples; 3: the mixed rest
+    Timed t(c, K_INTER, (max_mct[0] > 0) + (max_mct[1] > 0) + (max_mct[2] > 0) + (max_mcb > 0));
+    for (int t = 0; t < 3; t++)
+      if (max_mct[t] > 0) hr_launch(K_INTER, jd, n, s, c->stream, t, max_mct[t]);
+    if (max_mcb > 0) hr_launch(K_INTER, jd, n, s, c->stream, 3, max_mcb);
   }
   {
     int nl = 0;

@@ -26,6 +26,29 @@
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 
+// Wave-level helpers.  hr_uniform: a value known to be equal in all lanes, moved to a scalar
+// register.  hr_wave_sync: orders LDS traffic between the lanes of ONE wave (a wave executes its LDS
+// instructions in order, so this only has to stop the compiler from moving accesses across it).
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ int hr_uniform(int v) { return v; }
+__device__ __forceinline__ unsigned hr_uniform(unsigned v) { return v; }
+__device__ __forceinline__ void hr_wave_sync() { emu::current_block().wave_barrier[emu::wave()].wait(); }
+__device__ __forceinline__ unsigned hr_brev(unsigned v) {
+  unsigned r = 0;
+  for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
+  return r;
+}
+#else
+__device__ __forceinline__ int hr_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned hr_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ void hr_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ unsigned hr_brev(unsigned v) { return __brev(v); }
+#endif
+
 template <typename pel_t>
 __device__ __forceinline__ const pel_t *plane_c(const void *p) { return (const pel_t *)p; }
 
@@ -338,28 +361,29 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
   }
 }
 
-// k_inter_blk: regions with mixed motion.  One wave per 32x32 region, one lane per 4x4 unit.
+// k_inter_blk: 16x16 regions with mixed motion.  One wave per four regions, one lane per 4x4 unit.
 template <typename pel_t>
 __global__ __launch_bounds__(256) void k_inter_blk(const PicJob *jobs, SeqInfo s) {
   const PicJob &J = jobs[blockIdx.y];
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (r >= J.n_mc_blk) return;
   const McBlk b = J.mc_blk[r];
-  const int lane = threadIdx.x & 63;
-  const int ux = (b.x >> 2) + (lane & 7), uy = (b.y >> 2) + (lane >> 3);
+  const int u = threadIdx.x & 15;
+  const int ux = (b.x >> 2) + (u & 3), uy = (b.y >> 2) + (u >> 2);
   if (ux >= s.uw || uy >= s.uh) return;
   inter_unit<pel_t>(J, s, ux, uy);
 }
 
 // ---- k_inter_tile: regions with uniform motion, 8-bit pictures -----------------------------------------
-// One workgroup predicts a 32x32 luma region and its two 16x16 chroma regions as single blocks.
-//   phase H  every lane filters two rows x eight outputs horizontally, straight from the reference picture
-//            (one unaligned 16-byte load per row: 8 lanes cover a window row contiguously, so the loads
-//            coalesce), and stores the 16-bit intermediates of the two rows packed in one dword, P[pair][x];
+// One workgroup predicts a TS x TS luma region (TS = 64, 32, 16) and its two chroma regions as single blocks.
+//   phase H  work items of two window rows x eight outputs: the lane fetches 16 bytes of each row straight
+//            from the reference picture (unaligned loads; the lanes of a row are contiguous, so they
+//            coalesce; all of a lane's loads are issued before the first is used), filters horizontally and
+//            stores the 16-bit intermediates of the two rows packed in one dword, P[pair][x];
 //   phase V  one lane per column and four rows: the vertical filter as 2-way 16-bit dot products over the
 //            packed row pairs (odd rows use the tap pairs shifted by one), both lists accumulated in
 //            registers, then the uni- or bi-prediction rounding; the bytes go to an LDS tile;
-//   store    the tile is written out as dwords, 32 (16) bytes per row.
+//   store    the tile is written out as dwords.
 // Arithmetic as in interp_u8: samples biased by 128 so the horizontal sums ARE the reference's 14-bit
 // intermediates; TComInterpolationFilter.cpp:165-246, TComPrediction.cpp:413-507, TComYuv.cpp:520-584.
 #ifdef HEVCRECON_EMULATE
@@ -372,175 +396,262 @@ __device__ __forceinline__ int hr_sdot2(unsigned a, unsigned b, int c) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(hr_short2, a), __builtin_bit_cast(hr_short2, b), c, false);
 }
 #endif
+// Final rounding of the tile kernels: clip((v + off) >> sh) to a byte.  The shifted value is hidden from the
+// optimiser on purpose: hipcc (ROCm 7.2) otherwise fuses "shift, clamp to 0..255, pack two bytes" into
+// v_ashr_pk_u8_i32 and then ORs the other two bytes into the upper half of its result register, which that
+// instruction does not clear on gfx950 (the upper bytes of a negative input came out as 0xFF).
+__device__ __forceinline__ int tile_px(int v, int off, int sh) {
+  int x = (v + off) >> sh;
+#ifndef HEVCRECON_EMULATE
+  asm volatile("" : "+v"(x));
+#endif
+  return clip3i(0, 255, x);
+}
 __device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
 
-struct __attribute__((packed)) HrBytes16 { unsigned v[4]; };
-struct __attribute__((packed)) HrBytes12 { unsigned v[3]; };
+struct __attribute__((packed)) HrBytes16 {
+  unsigned v[4];
+};
 
-// NB bytes of row `row` starting at sample x0 (clamped into the row when !fast), as NB/4 dwords
-template <int ND>
-__device__ __forceinline__ void tile_row_load(const uint8_t *row, int x0, int pw, bool fast, unsigned w[ND]) {
+// 16 bytes of a picture row starting at sample x0; without `fast` every sample position is clamped into the row
+__device__ __forceinline__ void tile_row_load(const uint8_t *row, int x0, int pw, bool fast, unsigned w[4]) {
   if (fast) {
-    if constexpr (ND == 4) {
-      const HrBytes16 q = *(const HrBytes16 *)(row + x0);
+    const HrBytes16 q = *(const HrBytes16 *)(row + x0);
 #pragma unroll
-      for (int k = 0; k < 4; k++) w[k] = q.v[k];
-    } else {
-      const HrBytes12 q = *(const HrBytes12 *)(row + x0);
-#pragma unroll
-      for (int k = 0; k < 3; k++) w[k] = q.v[k];
-    }
+    for (int k = 0; k < 4; k++) w[k] = q.v[k];
   } else {
+    // (the volatile no-op pins the clamping arithmetic of this rare path inside the branch; left to itself the
+    // compiler computes all 16 clamped positions ahead of the branch, for every lane of every item)
+    int xb = x0;
+#ifndef HEVCRECON_EMULATE
+    asm volatile("" : "+v"(xb));
+#endif
 #pragma unroll
-    for (int k = 0; k < ND; k++) w[k] = 0;
+    for (int k = 0; k < 4; k++) w[k] = 0;
 #pragma unroll
-    for (int i = 0; i < 4 * ND; i++) w[i >> 2] |= (unsigned)row[clip3i(0, pw - 1, x0 + i)] << (8 * (i & 3));
+    for (int i = 0; i < 16; i++) w[i >> 2] |= (unsigned)row[clip3i(0, pw - 1, xb + i)] << (8 * (i & 3));
   }
 }
 
-#define MT_PY (20 * 32) /* luma row pairs x columns */
-#define MT_PC (10 * 16)
+// Packed tap tables (TLibCommon/TComInterpolationFilter.cpp:55-73), read with wave-uniform indices:
+// four signed bytes per dword for the horizontal byte dot products, 16-bit pairs for the vertical ones
+// ("even": taps (0,1)(2,3)...; "odd": the same taps shifted by one row, (-,0)(1,2)...(7,-)).
+#define HR_B4(a, b, c, d) (((unsigned)(a)&255u) | (((unsigned)(b)&255u) << 8) | (((unsigned)(c)&255u) << 16) | (((unsigned)(d)&255u) << 24))
+#define HR_P2(a, b) (((unsigned)(a)&0xffffu) | ((unsigned)(b) << 16))
+#define HR_L8(f, a, b, c, d, e, g, h, i)                                                                 \
+  { HR_B4(a, b, c, d), HR_B4(e, g, h, i), HR_P2(a, b), HR_P2(c, d), HR_P2(e, g), HR_P2(h, i), HR_P2(0, a), HR_P2(b, c), \
+    HR_P2(d, e), HR_P2(g, h), HR_P2(i, 0), 0 }
+#define HR_C4(a, b, c, d) { HR_B4(a, b, c, d), HR_P2(a, b), HR_P2(c, d), HR_P2(0, a), HR_P2(b, c), HR_P2(d, 0), 0, 0 }
+__constant__ unsigned kLumaTab[4][12] = {HR_L8(0, 0, 0, 0, 64, 0, 0, 0, 0), HR_L8(1, -1, 4, -10, 58, 17, -5, 1, 0),
+                                         HR_L8(2, -1, 4, -11, 40, 40, -11, 4, -1), HR_L8(3, 0, 1, -5, 17, 58, -10, 4, -1)};
+__constant__ unsigned kChromaTab[8][8] = {HR_C4(0, 64, 0, 0),    HR_C4(-2, 58, 10, -2), HR_C4(-4, 54, 16, -2), HR_C4(-6, 46, 28, -4),
+                                          HR_C4(-4, 36, 36, -4), HR_C4(-4, 28, 46, -6), HR_C4(-2, 16, 54, -4), HR_C4(-2, 10, 58, -2)};
 
-__global__ __launch_bounds__(256, 8) void k_inter_tile(const PicJob *jobs, SeqInfo s) {
-  __shared__ unsigned P_y[2][MT_PY];
-  __shared__ unsigned P_c[2][2][MT_PC];
-  __shared__ unsigned out_y[32 * 8];
-  __shared__ unsigned out_c[2][16 * 4];
+// first product of a dot-product chain.  (Not inline assembly with a literal zero accumulator: results of
+// the dot instructions need wait states before another VALU instruction reads them on this hardware, which the
+// compiler only inserts for instructions it has emitted itself.)
+__device__ __forceinline__ int hr_sdot4z(unsigned a, unsigned b) { return hr_sdot4(a, b, 0); }
+__device__ __forceinline__ int hr_sdot2z(unsigned a, unsigned b) { return hr_sdot2(a, b, 0); }
+
+template <int TS, int NTHR>
+__global__ __launch_bounds__(NTHR, (TS == 64 ? 5 : 8)) void k_inter_tile(const PicJob *jobs, SeqInfo s) {
+  constexpr int CS = TS / 2;                                     // chroma region size
+  constexpr int NPY = (TS + 8) / 2, OY = TS / 8, TY = NPY * OY;  // luma: row pairs, 8-output groups per row, items
+  constexpr int NPC = (CS + 4) / 2, OC = CS / 8, TC1 = NPC * OC, TC = 2 * TC1;  // chroma, both components
+  // With SEG the chroma items of a list start at a multiple of 64, so that a wave never mixes luma and chroma
+  // and everything that depends on the class stays in scalar registers.
+  constexpr bool SEG = TS >= 32;
+  constexpr int LYP = SEG ? (TY + 63) / 64 * 64 : TY;
+  constexpr int HIT = (LYP + TC + NTHR - 1) / NTHR;  // H items per lane and list
+  constexpr int LVL = TS == 64 ? 0 : TS == 32 ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) unsigned P_y[2][NPY * TS];
+  __shared__ __attribute__((aligned(16))) unsigned P_c[2][2][NPC * CS];
   const PicJob &J = jobs[blockIdx.y];
   // XCD-contiguous order: workgroups go to the 8 XCDs round-robin; consecutive regions share cache lines
-  const int n = J.n_mc_tile, per_xcd = (n + 7) >> 3;
+  const int n = J.n_mc_tile[LVL], per_xcd = (n + 7) >> 3;
   const int idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per_xcd || idx >= n) return;
-  const McTile t = J.mc_tile[idx];
+  const McTile t = J.mc_tile[LVL][idx];
   const int tid = threadIdx.x;
   const int rx = t.x, ry = t.y;
+  const int nl = (t.ref[0] >= 0 ? 1 : 0) + (t.ref[1] >= 0 ? 1 : 0);
+  // a list with a zero vertical fraction needs no vertical filter: its rows outside the block are never read
+  const bool vid_y[2] = {(t.mv[0][1] & 3) == 0, (t.mv[1][1] & 3) == 0};
+  const bool vid_c[2] = {(t.mv[0][1] & 7) == 0, (t.mv[1][1] & 7) == 0};
 
   // ---- phase H ----
-  if (tid < 160) {
-    const int l = tid >= 80 ? 1 : 0, k = tid - 80 * l;
-    if (t.ref[l] >= 0) {
-      const int p = k >> 2, o = k & 3;
-      const uint8_t *ref = (const uint8_t *)J.ref[l][t.ref[l]][0];
-      const int mvx = t.mv[l][0], mvy = t.mv[l][1];
-      int tx[8];
-      luma_taps(mvx & 3, tx);
-      const unsigned tlo = pack4(tx[0], tx[1], tx[2], tx[3]), thi = pack4(tx[4], tx[5], tx[6], tx[7]);
-      const int wx0 = rx + (mvx >> 2) - 3, wy0 = ry + (mvy >> 2) - 3;
-      const bool fast = wx0 >= 0 && wx0 + 38 < s.w;
-      int h[2][8];
+  // item -> (luma/chroma, component, row pair p, output group o) of list l
+#define MT_DECODE                                                                                \
+  const int item = tid + it * NTHR;                                                              \
+  const bool chroma = (SEG ? hr_uniform(item & ~63) : item) >= LYP;                              \
+  const int k = item - (chroma ? LYP : 0);                                                       \
+  const int comp = chroma && k >= TC1 ? 1 : 0, kk = k - comp * TC1;                              \
+  const int p = chroma ? kk / OC : kk / OY, o = chroma ? kk % OC : kk % OY;                      \
+  const bool live = t.ref[l] >= 0 && k < (chroma ? TC : TY) &&                                   \
+                    !(chroma ? vid_c[l] && p > CS / 2 : vid_y[l] && (p < 1 || p > TS / 2 + 1));
+  unsigned w[2][HIT][2][4];
 #pragma unroll
-      for (int rr = 0; rr < 2; rr++) {
-        const int r = min(2 * p + rr, 38);
-        const uint8_t *row = ref + (size_t)clip3i(0, s.h - 1, wy0 + r) * s.stride_y;
-        unsigned w[4];
-        tile_row_load<4>(row, wx0 + 8 * o, s.w, fast, w);
+  for (int l = 0; l < 2; l++) {
+    const int ri = t.ref[l] >= 0 ? t.ref[l] : 0;
+    const int mvx = t.mv[l][0], mvy = t.mv[l][1];
+    const int wx0 = rx + (mvx >> 2) - 3, wy0 = ry + (mvy >> 2) - 3;
+    const int cwx0 = (rx >> 1) + (mvx >> 3) - 1, cwy0 = (ry >> 1) + (mvy >> 3) - 1;
+    const bool fast_y = wx0 >= 0 && wx0 + TS + 6 < s.w, fast_c = cwx0 >= 0 && cwx0 + CS + 2 < s.cw;
 #pragma unroll
-        for (int q = 0; q < 4; q++) w[q] ^= 0x80808080u;
-        unsigned a[12];
+    for (int it = 0; it < HIT; it++) {
+      MT_DECODE
+      if (live) {
+        const uint8_t *base = (const uint8_t *)(chroma ? (comp ? J.ref[l][ri][2] : J.ref[l][ri][1]) : J.ref[l][ri][0]);
+        const int stride = chroma ? s.stride_c : s.stride_y, pw = chroma ? s.cw : s.w, ph = chroma ? s.ch : s.h;
+        const int x0 = (chroma ? cwx0 : wx0) + 8 * o, y0 = chroma ? cwy0 : wy0;
+        const int last = chroma ? CS + 2 : TS + 6;
+        const bool fast = chroma ? fast_c : fast_y;
 #pragma unroll
-        for (int i = 0; i < 12; i++) a[i] = (i & 3) ? hr_alignbyte(w[(i >> 2) + 1], w[i >> 2], i & 3) : w[i >> 2];
-#pragma unroll
-        for (int i = 0; i < 8; i++) h[rr][i] = hr_sdot4(a[i + 4], thi, hr_sdot4(a[i], tlo, 0));
-      }
-      unsigned *dst = &P_y[l][p * 32 + 8 * o];
-#pragma unroll
-      for (int i = 0; i < 8; i++) dst[i] = pack16(h[0][i], h[1][i]);
-    }
-  } else if (tid < 240) {
-    const int l = tid >= 200 ? 1 : 0, k = tid - 160 - 40 * l;
-    if (t.ref[l] >= 0) {
-      const int comp = k >= 20 ? 1 : 0, kk = k - 20 * comp;
-      const int p = kk >> 1, o = kk & 1;
-      const uint8_t *ref = (const uint8_t *)J.ref[l][t.ref[l]][1 + comp];
-      const int mvx = t.mv[l][0], mvy = t.mv[l][1];
-      int tx[4];
-      chroma_taps(mvx & 7, tx);
-      const unsigned tc = pack4(tx[0], tx[1], tx[2], tx[3]);
-      const int wx0 = (rx >> 1) + (mvx >> 3) - 1, wy0 = (ry >> 1) + (mvy >> 3) - 1;
-      const bool fast = wx0 >= 0 && wx0 + 18 < s.cw;
-      int h[2][8];
-#pragma unroll
-      for (int rr = 0; rr < 2; rr++) {
-        const int r = min(2 * p + rr, 18);
-        const uint8_t *row = ref + (size_t)clip3i(0, s.ch - 1, wy0 + r) * s.stride_c;
-        unsigned w[3];
-        tile_row_load<3>(row, wx0 + 8 * o, s.cw, fast, w);
-#pragma unroll
-        for (int q = 0; q < 3; q++) w[q] ^= 0x80808080u;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const unsigned a = (i & 3) ? hr_alignbyte(w[(i >> 2) + 1], w[i >> 2], i & 3) : w[i >> 2];
-          h[rr][i] = hr_sdot4(a, tc, 0);
+        for (int rr = 0; rr < 2; rr++) {
+          const int r = min(2 * p + rr, last);
+          tile_row_load(base + (size_t)clip3i(0, ph - 1, y0 + r) * stride, x0, pw, fast, w[l][it][rr]);
         }
       }
-      unsigned *dst = &P_c[l][comp][p * 16 + 8 * o];
-#pragma unroll
-      for (int i = 0; i < 8; i++) dst[i] = pack16(h[0][i], h[1][i]);
     }
   }
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    const unsigned *lt = kLumaTab[t.mv[l][0] & 3], *ct = kChromaTab[t.mv[l][0] & 7];
+    const unsigned c_lo = lt[0], c_hi = lt[1], c4 = ct[0];
+#pragma unroll
+    for (int it = 0; it < HIT; it++) {
+      MT_DECODE
+      if (live) {
+        int h[2][8];
+        if (!chroma) {
+#pragma unroll
+          for (int rr = 0; rr < 2; rr++) {
+            unsigned x[4], a[12];
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = w[l][it][rr][i] ^ 0x80808080u;
+#pragma unroll
+            for (int i = 0; i < 12; i++) a[i] = (i & 3) ? hr_alignbyte(x[(i >> 2) + 1], x[i >> 2], i & 3) : x[i >> 2];
+#pragma unroll
+            for (int i = 0; i < 8; i++) h[rr][i] = hr_sdot4(a[i + 4], c_hi, hr_sdot4z(a[i], c_lo));
+          }
+          uint4 *dst = (uint4 *)&P_y[l][p * TS + 8 * o];
+          dst[0] = make_uint4(pack16(h[0][0], h[1][0]), pack16(h[0][1], h[1][1]), pack16(h[0][2], h[1][2]), pack16(h[0][3], h[1][3]));
+          dst[1] = make_uint4(pack16(h[0][4], h[1][4]), pack16(h[0][5], h[1][5]), pack16(h[0][6], h[1][6]), pack16(h[0][7], h[1][7]));
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 2; rr++) {
+            unsigned x[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) x[i] = w[l][it][rr][i] ^ 0x80808080u;
+#pragma unroll
+            for (int i = 0; i < 8; i++) h[rr][i] = hr_sdot4z((i & 3) ? hr_alignbyte(x[(i >> 2) + 1], x[i >> 2], i & 3) : x[i >> 2], c4);
+          }
+          uint4 *dst = (uint4 *)&P_c[l][0][comp * (NPC * CS) + p * CS + 8 * o];
+          dst[0] = make_uint4(pack16(h[0][0], h[1][0]), pack16(h[0][1], h[1][1]), pack16(h[0][2], h[1][2]), pack16(h[0][3], h[1][3]));
+          dst[1] = make_uint4(pack16(h[0][4], h[1][4]), pack16(h[0][5], h[1][5]), pack16(h[0][6], h[1][6]), pack16(h[0][7], h[1][7]));
+        }
+      }
+    }
+  }
+#undef MT_DECODE
   __syncthreads();
 
-  // ---- phase V ----
-  const bool bi = t.ref[0] >= 0 && t.ref[1] >= 0;
+  // ---- phase V: one lane per two rows x four columns, result stored as one dword per row ----
+  const bool bi = nl == 2;
   // 8-bit samples: uni (v + 8192 + 32) >> 6, bi (v0 + v1 + 16384 + 64) >> 7
   const int fsh = bi ? 7 : 6, foff = bi ? 16384 + 64 : 8192 + 32;
-  {
-    const int x = tid & 31, g = tid >> 5;
-    int acc[4] = {0, 0, 0, 0};
+  constexpr int LT = TS * TS / 8, CT = 2 * CS * CS / 8;  // luma and chroma work items
+  for (int v0 = 0; v0 < LT + CT; v0 += NTHR) {
+    const int v = v0 + tid;
+    const bool chroma = (SEG ? hr_uniform(v & ~63) : v) >= LT;
+    if (!chroma) {
+      const int q = v % (TS / 4), rp = v / (TS / 4);
+      int acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-    for (int l = 0; l < 2; l++) {
-      if (t.ref[l] < 0) continue;
-      int ty[8];
-      luma_taps(t.mv[l][1] & 3, ty);
-      const unsigned e0 = pack16(ty[0], ty[1]), e1 = pack16(ty[2], ty[3]), e2 = pack16(ty[4], ty[5]), e3 = pack16(ty[6], ty[7]);
-      const unsigned o0 = pack16(0, ty[0]), o1 = pack16(ty[1], ty[2]), o2 = pack16(ty[3], ty[4]), o3 = pack16(ty[5], ty[6]),
-                     o4 = pack16(ty[7], 0);
-      unsigned q[6];
+      for (int l = 0; l < 2; l++) {
+        if (t.ref[l] < 0) continue;
+        const uint4 *src = (const uint4 *)&P_y[l][rp * TS + 4 * q];
+        if (vid_y[l]) {
+          // rows j+3 and j+4 of the window are the block's rows j and j+1
+          const uint4 a = src[(TS / 4) * 1], b = src[(TS / 4) * 2];
+          const unsigned qa[4] = {a.x, a.y, a.z, a.w}, qb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-      for (int i = 0; i < 6; i++) q[i] = P_y[l][(2 * g + i) * 32 + x];
-      acc[0] += hr_sdot2(q[3], e3, hr_sdot2(q[2], e2, hr_sdot2(q[1], e1, hr_sdot2(q[0], e0, 0)))) >> 6;
-      acc[1] += hr_sdot2(q[4], o4, hr_sdot2(q[3], o3, hr_sdot2(q[2], o2, hr_sdot2(q[1], o1, hr_sdot2(q[0], o0, 0))))) >> 6;
-      acc[2] += hr_sdot2(q[4], e3, hr_sdot2(q[3], e2, hr_sdot2(q[2], e1, hr_sdot2(q[1], e0, 0)))) >> 6;
-      acc[3] += hr_sdot2(q[5], o4, hr_sdot2(q[4], o3, hr_sdot2(q[3], o2, hr_sdot2(q[2], o1, hr_sdot2(q[1], o0, 0))))) >> 6;
+          for (int c = 0; c < 4; c++) {
+            acc[0][c] += (int)qa[c] >> 16;
+            acc[1][c] += (int)(int16_t)(qb[c] & 0xffff);
+          }
+        } else {
+          const unsigned *lt = kLumaTab[t.mv[l][1] & 3];
+          const unsigned e0 = lt[2], e1 = lt[3], e2 = lt[4], e3 = lt[5], o0 = lt[6], o1 = lt[7], o2 = lt[8], o3 = lt[9], o4 = lt[10];
+          unsigned qq[5][4];
+#pragma unroll
+          for (int i = 0; i < 5; i++) {
+            const uint4 a = src[(TS / 4) * i];
+            qq[i][0] = a.x, qq[i][1] = a.y, qq[i][2] = a.z, qq[i][3] = a.w;
+          }
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            acc[0][c] += hr_sdot2(qq[3][c], e3, hr_sdot2(qq[2][c], e2, hr_sdot2(qq[1][c], e1, hr_sdot2z(qq[0][c], e0)))) >> 6;
+            acc[1][c] +=
+                hr_sdot2(qq[4][c], o4, hr_sdot2(qq[3][c], o3, hr_sdot2(qq[2][c], o2, hr_sdot2(qq[1][c], o1, hr_sdot2z(qq[0][c], o0))))) >> 6;
+          }
+        }
+      }
+      if (v < LT && rx + 4 * q < s.w) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int y = ry + 2 * rp + j;
+          if (y < s.h)
+            *(unsigned *)((uint8_t *)J.rec[0] + (size_t)y * s.stride_y + rx + 4 * q) =
+                pack4(tile_px(acc[j][0], foff, fsh), tile_px(acc[j][1], foff, fsh), tile_px(acc[j][2], foff, fsh),
+                      tile_px(acc[j][3], foff, fsh));
+        }
+      }
+    } else {
+      const int vc = v - LT;
+      const int comp = vc >= CT / 2 ? 1 : 0, r = vc - comp * (CT / 2);
+      const int q = r % (CS / 4), rp = r / (CS / 4);
+      int acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+      for (int l = 0; l < 2; l++) {
+        if (t.ref[l] < 0 || vc >= CT) continue;
+        const uint4 *src = (const uint4 *)&P_c[l][0][comp * (NPC * CS) + rp * CS + 4 * q];
+        if (vid_c[l]) {
+          const uint4 a = src[0], b = src[CS / 4];
+          const unsigned qa[4] = {a.x, a.y, a.z, a.w}, qb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            acc[0][c] += (int)qa[c] >> 16;
+            acc[1][c] += (int)(int16_t)(qb[c] & 0xffff);
+          }
+        } else {
+          const unsigned *ct = kChromaTab[t.mv[l][1] & 7];
+          const unsigned e0 = ct[1], e1 = ct[2], o0 = ct[3], o1 = ct[4], o2 = ct[5];
+          unsigned qq[3][4];
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            const uint4 a = src[(CS / 4) * i];
+            qq[i][0] = a.x, qq[i][1] = a.y, qq[i][2] = a.z, qq[i][3] = a.w;
+          }
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            acc[0][c] += hr_sdot2(qq[1][c], e1, hr_sdot2z(qq[0][c], e0)) >> 6;
+            acc[1][c] += hr_sdot2(qq[2][c], o2, hr_sdot2(qq[1][c], o1, hr_sdot2z(qq[0][c], o0))) >> 6;
+          }
+        }
+      }
+      const int cx = (rx >> 1) + 4 * q;
+      if (vc < CT && cx < s.cw) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int y = (ry >> 1) + 2 * rp + j;
+          if (y < s.ch)
+            *(unsigned *)((uint8_t *)J.rec[1 + comp] + (size_t)y * s.stride_c + cx) =
+                pack4(tile_px(acc[j][0], foff, fsh), tile_px(acc[j][1], foff, fsh), tile_px(acc[j][2], foff, fsh),
+                      tile_px(acc[j][3], foff, fsh));
+        }
+      }
     }
-    uint8_t *ob = (uint8_t *)out_y;
-#pragma unroll
-    for (int j = 0; j < 4; j++) ob[(4 * g + j) * 32 + x] = (uint8_t)clip3i(0, 255, (acc[j] + foff) >> fsh);
-  }
-  if (tid < 128) {
-    const int comp = tid >> 6, x = tid & 15, g = (tid >> 4) & 3;
-    int acc[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int l = 0; l < 2; l++) {
-      if (t.ref[l] < 0) continue;
-      int ty[4];
-      chroma_taps(t.mv[l][1] & 7, ty);
-      const unsigned e0 = pack16(ty[0], ty[1]), e1 = pack16(ty[2], ty[3]);
-      const unsigned o0 = pack16(0, ty[0]), o1 = pack16(ty[1], ty[2]), o2 = pack16(ty[3], 0);
-      unsigned q[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) q[i] = P_c[l][comp][(2 * g + i) * 16 + x];
-      acc[0] += hr_sdot2(q[1], e1, hr_sdot2(q[0], e0, 0)) >> 6;
-      acc[1] += hr_sdot2(q[2], o2, hr_sdot2(q[1], o1, hr_sdot2(q[0], o0, 0))) >> 6;
-      acc[2] += hr_sdot2(q[2], e1, hr_sdot2(q[1], e0, 0)) >> 6;
-      acc[3] += hr_sdot2(q[3], o2, hr_sdot2(q[2], o1, hr_sdot2(q[1], o0, 0))) >> 6;
-    }
-    uint8_t *ob = (uint8_t *)out_c[comp];
-#pragma unroll
-    for (int j = 0; j < 4; j++) ob[(4 * g + j) * 16 + x] = (uint8_t)clip3i(0, 255, (acc[j] + foff) >> fsh);
-  }
-  __syncthreads();
-
-  // ---- store ----
-  {
-    const int row = tid >> 3, dw = tid & 7;
-    if (ry + row < s.h && rx + 4 * dw < s.w)
-      *(unsigned *)((uint8_t *)J.rec[0] + (size_t)(ry + row) * s.stride_y + rx + 4 * dw) = out_y[row * 8 + dw];
-  }
-  if (tid < 128) {
-    const int comp = tid >> 6, row = (tid >> 2) & 15, dw = tid & 3;
-    const int cx = (rx >> 1) + 4 * dw, cy = (ry >> 1) + row;
-    if (cy < s.ch && cx < s.cw) *(unsigned *)((uint8_t *)J.rec[1 + comp] + (size_t)cy * s.stride_c + cx) = out_c[comp][row * 4 + dw];
   }
 }
 
@@ -652,29 +763,6 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
     for (int x = 0; x < N; x++) o[x] = (pel_t)clip3i(0, maxv, (int)o[x] + res[x]);
   }
 }
-
-// Wave-level helpers of k_intra.  hr_uniform: a value known to be equal in all lanes, moved to a scalar
-// register.  hr_wave_sync: orders LDS traffic between the lanes of ONE wave (a wave executes its LDS
-// instructions in order, so this only has to stop the compiler from moving accesses across it).
-#ifdef HEVCRECON_EMULATE
-__device__ __forceinline__ int hr_uniform(int v) { return v; }
-__device__ __forceinline__ unsigned hr_uniform(unsigned v) { return v; }
-__device__ __forceinline__ void hr_wave_sync() { emu::current_block().wave_barrier[emu::wave()].wait(); }
-__device__ __forceinline__ unsigned hr_brev(unsigned v) {
-  unsigned r = 0;
-  for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
-  return r;
-}
-#else
-__device__ __forceinline__ int hr_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ unsigned hr_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ void hr_wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ __forceinline__ unsigned hr_brev(unsigned v) { return __brev(v); }
-#endif
 
 // Angular prediction of one sample from main-reference index i0 (>= 0 for positive angles) and fraction df.
 __device__ __forceinline__ int intra_ang_pos(const int *cn, int sgn, int i0, int df) {
@@ -1265,11 +1353,15 @@ template <typename pel_t>
 static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t st, int arg, int arg2) {
   switch (kind) {
     case K_INTER:
-      // arg = max number of uniform regions over the batch, arg2 = max number of mixed regions.
-      // Tile grid.x is a multiple of 8, so that blockIdx.x & 7 is the XCD for every picture of the batch.
-      if constexpr (sizeof(pel_t) == 1)
-        if (arg > 0) LAUNCH(k_inter_tile, dim3((arg + 7) / 8 * 8, n), dim3(256), st, jobs, s);
-      if (arg2 > 0) LAUNCH(k_inter_blk<pel_t>, dim3((arg2 + 3) / 4, n), dim3(256), st, jobs, s);
+      // arg = 0..2: uniform regions of 64 / 32 / 16 samples, 3: mixed regions; arg2 = their largest count over the
+      // batch.  Tile grid.x is a multiple of 8, so that blockIdx.x & 7 is the XCD for every picture of the batch.
+      if constexpr (sizeof(pel_t) == 1) {
+        const dim3 g((arg2 + 7) / 8 * 8, n);
+        if (arg == 0) LAUNCH((k_inter_tile<64, 256>), g, dim3(256), st, jobs, s);
+        if (arg == 1) LAUNCH((k_inter_tile<32, 256>), g, dim3(256), st, jobs, s);
+        if (arg == 2) LAUNCH((k_inter_tile<16, 64>), g, dim3(64), st, jobs, s);
+      }
+      if (arg == 3) LAUNCH(k_inter_blk<pel_t>, dim3((arg2 + 15) / 16, n), dim3(256), st, jobs, s);
       break;
     case K_TRANSFORM: {
       // arg = log2 size, arg2 = max number of blocks of that size over the batch

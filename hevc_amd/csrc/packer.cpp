@@ -328,71 +328,96 @@ bool PackedPicture::finish(const hevcrecon_pic_params *p) {
   return true;
 }
 
-// Sorts the 32x32 luma regions that hold inter blocks into the two motion-compensation lists.  A region is
-// uniform when every 4x4 unit inside the picture is inter and resolves to the same prediction: same
-// references, same vectors after TComDataCU::clipMv (TLibCommon/TComDataCU.cpp:3207-3219, the range depends
-// on the unit's coding-unit origin), same outcome of TComPrediction::xCheckIdenticalMotion
-// (TLibCommon/TComPrediction.cpp:396-411).
-void PackedPicture::build_mc_lists() {
-  mc_tile.clear();
-  mc_blk.clear();
-  if (pp.slice_type == 2) return;
-  const bool tiles_ok = seq.bd_y <= 8 && seq.bd_c <= 8;  // the tile kernel works on byte planes
-  const int rw = (seq.w + 31) / 32, rh = (seq.h + 31) / 32;
-  for (int ry = 0; ry < rh; ry++)
-    for (int rx = 0; rx < rw; rx++) {
-      bool any_inter = false, uniform = true, have = false;
-      McTile first;
-      std::memset(&first, 0, sizeof(first));
-      for (int uy = ry * 8; uy < std::min(ry * 8 + 8, seq.uh); uy++)
-        for (int ux = rx * 8; ux < std::min(rx * 8 + 8, seq.uw); ux++) {
-          const Part4 &p = rec4[(size_t)uy * seq.uw + ux];
-          if (p.flags & P4_INTRA) {
-            uniform = false;
-            continue;
-          }
-          any_inter = true;
-          if (!uniform) continue;
-          const int cusize = 64 >> (p.flags & P4_DEPTH_MASK);
-          const int cux = (ux * 4) & ~(cusize - 1), cuy = (uy * 4) & ~(cusize - 1);
-          const int hmax = (seq.w + 8 - cux - 1) * 4, hmin = (-64 - 8 - cux + 1) * 4;
-          const int vmax = (seq.h + 8 - cuy - 1) * 4, vmin = (-64 - 8 - cuy + 1) * 4;
-          bool use[2] = {p.ref_idx[0] >= 0, p.ref_idx[1] >= 0};
-          if (use[0] && use[1] && pp.slice_type == 0 && p.ref_idx[0] < HR_MAX_REFS && p.ref_idx[1] < HR_MAX_REFS &&
-              pp.ref_poc[0][p.ref_idx[0]] == pp.ref_poc[1][p.ref_idx[1]] && p.mv[0][0] == p.mv[1][0] && p.mv[0][1] == p.mv[1][1])
-            use[1] = false;
-          if (!use[0] && !use[1]) {
-            uniform = false;
-            continue;
-          }
-          McTile t;
-          std::memset(&t, 0, sizeof(t));
-          t.x = (uint16_t)(rx * 32);
-          t.y = (uint16_t)(ry * 32);
-          for (int l = 0; l < 2; l++) {
-            t.ref[l] = use[l] ? p.ref_idx[l] : (int8_t)-1;
-            if (use[l]) {
-              t.mv[l][0] = (int16_t)std::min(hmax, std::max(hmin, (int)p.mv[l][0]));
-              t.mv[l][1] = (int16_t)std::min(vmax, std::max(vmin, (int)p.mv[l][1]));
-            }
-          }
-          if (!have) {
-            first = t;
-            have = true;
-          } else if (std::memcmp(&first, &t, sizeof(t)) != 0) {
-            uniform = false;
-          }
+// Sorts the picture's inter blocks into the motion-compensation lists.  A square region is uniform when every
+// 4x4 unit of it inside the picture is inter and resolves to the same prediction: same references, same
+// vectors after TComDataCU::clipMv (TLibCommon/TComDataCU.cpp:3207-3219, the range depends on the unit's
+// coding-unit origin), same outcome of TComPrediction::xCheckIdenticalMotion
+// (TLibCommon/TComPrediction.cpp:396-411).  Every CTU is tried whole, then by 32x32 quadrants, then by 16x16
+// blocks; what is left goes to mc_blk (16x16 granularity, predicted unit by unit).
+namespace {
+enum { MC_NONE, MC_UNIFORM, MC_MIXED };
+}
+
+int PackedPicture::classify_mc(int x0, int y0, int size, McTile *out) const {
+  bool any_inter = false, uniform = true, have = false;
+  McTile first;
+  std::memset(&first, 0, sizeof(first));
+  const int ux1 = std::min((x0 + size) >> 2, seq.uw), uy1 = std::min((y0 + size) >> 2, seq.uh);
+  for (int uy = y0 >> 2; uy < uy1; uy++)
+    for (int ux = x0 >> 2; ux < ux1; ux++) {
+      const Part4 &p = rec4[(size_t)uy * seq.uw + ux];
+      if (p.flags & P4_INTRA) {
+        uniform = false;
+        continue;
+      }
+      any_inter = true;
+      if (!uniform) continue;
+      const int cusize = 64 >> (p.flags & P4_DEPTH_MASK);
+      const int cux = (ux * 4) & ~(cusize - 1), cuy = (uy * 4) & ~(cusize - 1);
+      const int hmax = (seq.w + 8 - cux - 1) * 4, hmin = (-64 - 8 - cux + 1) * 4;
+      const int vmax = (seq.h + 8 - cuy - 1) * 4, vmin = (-64 - 8 - cuy + 1) * 4;
+      bool use[2] = {p.ref_idx[0] >= 0, p.ref_idx[1] >= 0};
+      if (use[0] && use[1] && pp.slice_type == 0 && p.ref_idx[0] < HR_MAX_REFS && p.ref_idx[1] < HR_MAX_REFS &&
+          pp.ref_poc[0][p.ref_idx[0]] == pp.ref_poc[1][p.ref_idx[1]] && p.mv[0][0] == p.mv[1][0] && p.mv[0][1] == p.mv[1][1])
+        use[1] = false;
+      if (!use[0] && !use[1]) {
+        uniform = false;
+        continue;
+      }
+      McTile t;
+      std::memset(&t, 0, sizeof(t));
+      t.x = (uint16_t)x0;
+      t.y = (uint16_t)y0;
+      for (int l = 0; l < 2; l++) {
+        t.ref[l] = use[l] ? p.ref_idx[l] : (int8_t)-1;
+        if (use[l]) {
+          t.mv[l][0] = (int16_t)std::min(hmax, std::max(hmin, (int)p.mv[l][0]));
+          t.mv[l][1] = (int16_t)std::min(vmax, std::max(vmin, (int)p.mv[l][1]));
         }
-      if (!any_inter) continue;
-      if (uniform && have && tiles_ok) {
-        mc_tile.push_back(first);
-      } else {
-        McBlk b;
-        b.x = (uint16_t)(rx * 32);
-        b.y = (uint16_t)(ry * 32);
-        mc_blk.push_back(b);
+      }
+      if (!have) {
+        first = t;
+        have = true;
+      } else if (std::memcmp(&first, &t, sizeof(t)) != 0) {
+        uniform = false;
       }
     }
+  if (!any_inter) return MC_NONE;
+  if (uniform && have) {
+    *out = first;
+    return MC_UNIFORM;
+  }
+  return MC_MIXED;
+}
+
+void PackedPicture::split_mc(int x0, int y0, int level) {
+  if (x0 >= seq.w || y0 >= seq.h) return;
+  const int size = 64 >> level;
+  const bool tiles_ok = seq.bd_y <= 8 && seq.bd_c <= 8;  // the tile kernels work on byte planes
+  McTile t;
+  const int kind = classify_mc(x0, y0, size, &t);
+  if (kind == MC_NONE) return;
+  if (kind == MC_UNIFORM && tiles_ok) {
+    mc_tile[level].push_back(t);
+    return;
+  }
+  if (level == 2) {
+    McBlk b;
+    b.x = (uint16_t)x0;
+    b.y = (uint16_t)y0;
+    mc_blk.push_back(b);
+    return;
+  }
+  const int h = size >> 1;
+  for (int q = 0; q < 4; q++) split_mc(x0 + (q & 1) * h, y0 + (q >> 1) * h, level + 1);
+}
+
+void PackedPicture::build_mc_lists() {
+  for (int i = 0; i < 3; i++) mc_tile[i].clear();
+  mc_blk.clear();
+  if (pp.slice_type == 2) return;
+  for (int cy = 0; cy < seq.ctus_h; cy++)
+    for (int cx = 0; cx < seq.ctus_w; cx++) split_mc(cx * 64, cy * 64, 0);
 }
 
 int64_t PackedPicture::algorithmic_bytes() const {

@@ -20,8 +20,8 @@ struct PackedPicture {
   std::vector<uint16_t> lvl_counts; // per CTU, per local level: number of blocks
   std::vector<int32_t> wave_off;    // n_waves + 1 offsets into ictu
   std::vector<SaoCtu> sao;
-  std::vector<McTile> mc_tile;      // filled by finish(): regions predicted as one block
-  std::vector<McBlk> mc_blk;        // filled by finish(): regions predicted unit by unit
+  std::vector<McTile> mc_tile[3];   // filled by finish(): 64x64 / 32x32 / 16x16 regions predicted as one block
+  std::vector<McBlk> mc_blk;        // filled by finish(): 16x16 regions predicted unit by unit
   int max_ref_idx[2];               // largest reference index used by an inter block, per list (-1: none)
   bool inter_without_ref;           // an inter block with no reference at all (corrupt input)
   int64_t mc_ref_samples;           // luma+chroma samples predicted, counted once per reference used
@@ -49,6 +49,8 @@ struct PackedPicture {
   void emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z, int zcu, int x, int y, int log2n, int mode);
   int coding_order(int ux, int uy) const;
   void build_mc_lists();
+  void split_mc(int x0, int y0, int level);
+  int classify_mc(int x0, int y0, int size, McTile *out) const;
 };
 
 #endif

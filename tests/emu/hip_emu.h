@@ -15,6 +15,7 @@
 #define HIP_EMU_H
 
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
@@ -40,6 +41,7 @@ struct dim3 {
 };
 struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
+inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 
 typedef int hipError_t;
 typedef void *hipStream_t;
