@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=8, help="independent streams per GPU")
+    ap.add_argument("--contexts", type=int, default=1, help="engine contexts (HIP streams) the streams of this GPU are spread over")
     ap.add_argument("--fixture", default="randomaccess_main_1920x1080")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -108,7 +109,10 @@ def main():
     seq = syntax.read_dump(os.path.join(ROOT, "tests", "golden", args.fixture + ".syn.xz"))
     sp = seq.seq_params
     npic, S = len(seq.pictures), args.streams
-    eng = engine.Engine(sp, device=local_rank)
+    C = max(1, min(args.contexts, S))
+    engs = [engine.Engine(sp, device=local_rank) for _ in range(C)]
+    eng = engs[0]
+    ctx_of = [s * C // S for s in range(S)]  # stream -> context
 
     # ---- pack every picture of every stream and make it resident in HBM (untimed) ----
     syns = [[None] * S for _ in range(npic)]
@@ -116,20 +120,28 @@ def main():
     for t, pic in enumerate(seq.pictures):
         pic.ctu_structs()
         for s in range(S):
-            syns[t][s] = eng.new_syntax().pack(clone_for_stream(pic, s))
+            syns[t][s] = engs[ctx_of[s]].new_syntax().pack(clone_for_stream(pic, s))
         stats.append(syns[t][0].stats())
         sao_flags.append(bool(pic.pic_params.sao_luma or pic.pic_params.sao_chroma))
         pic.drop_ctypes()
     ids = [[pic.pic_id + s * ID_STRIDE for s in range(S)] for pic in seq.pictures]
     alg_bytes_stream = sum(syns[t][0].algorithmic_bytes() for t in range(npic))
-    eng.synchronize()
+    groups = [[s for s in range(S) if ctx_of[s] == c] for c in range(C)]
+    for e in engs:
+        e.synchronize()
+
+    prepared = [[engs[c].prepare_batch([syns[t][s] for s in groups[c]], [ids[t][s] for s in groups[c]]) for c in range(C)]
+                for t in range(npic)]
 
     def one_step():
+        # contexts run on their own HIP streams: their kernels overlap on the GPU
         for t in range(npic):
-            eng.reconstruct_batch(syns[t], ids[t])
+            for c in range(C):
+                engs[c].reconstruct_prepared(prepared[t][c])
 
     def sync():
-        eng.synchronize()
+        for e in engs:
+            e.synchronize()
         if dist is not None:
             import torch
 
@@ -155,27 +167,32 @@ def main():
     # reference decoder's MD5 right after its batch (the decoder recycles picture ids, so the check cannot wait)
     bd = [sp.bit_depth_luma, sp.bit_depth_chroma, sp.bit_depth_chroma]
     for t, pic in enumerate(seq.pictures):
-        eng.reconstruct_batch(syns[t], ids[t])
+        for c in range(C):
+            engs[c].reconstruct_prepared(prepared[t][c])
         for s in sorted({0, S - 1}):
-            planes = eng.download(ids[t][s])
+            planes = engs[ctx_of[s]].download(ids[t][s])
             got = [syntax.plane_md5(planes[c], bd[c]) for c in range(3)]
             if got != pic.stage_md5[2]:
                 raise SystemExit("bench: stream %d POC %d differs from the reference decoder's MD5" % (s, pic.poc))
 
     # ---- per-kernel time with HIP events on the engine's stream (one extra, untimed step) ----
+    # (first context only, scaled by nothing: with several contexts the kernels of different contexts overlap,
+    # so per-kernel times are taken from a single-context pass over that context's streams)
     eng.profile_enable(True)
-    one_step()
+    for t in range(npic):
+        eng.reconstruct_prepared(prepared[t][0])
     prof = eng.profile_read()
     eng.profile_enable(False)
+    S_prof = len(groups[0])
     kb = kernel_bytes(seq, stats, sao_flags)
     kernels = {}
     for name, nbytes in kb.items():
         ms, launches = prof[name]
         kernels[name] = {"ms_per_step": round(ms, 4), "launches": int(launches),
-                         "alg_gbps": round(nbytes * S / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}
+                         "alg_gbps": round(nbytes * S_prof / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}
     dom = max(kb, key=lambda k: prof[k][0])
     dom_ms, dom_launches = prof[dom]
-    achieved = kb[dom] * S / (dom_ms * 1e-3) / 1e9
+    achieved = kb[dom] * S_prof / (dom_ms * 1e-3) / 1e9
     gpu_ms = sum(prof[k][0] for k in kb)
 
     frames_total = npic * S * args.steps * world
@@ -195,9 +212,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": "%dx%d %d-frame RA stream (encoder_randomaccess_main.cfg), %d independent streams per GPU, "
                                "stream-sharded, no collectives" % (sp.width, sp.height, npic, S),
-                   "streams_per_gpu": S, "frames_per_stream": npic, "md5_exact": True},
+                   "streams_per_gpu": S, "contexts_per_gpu": C, "frames_per_stream": npic, "md5_exact": True},
         "recon_alg_gbps": round(alg_bytes_stream * S * args.steps / elapsed / 1e9, 2),
-        "recon_alg_gbps_gpu_time": round(alg_bytes_stream * S / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None,
+        "recon_alg_gbps_gpu_time": round(alg_bytes_stream * S_prof / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None,
         "alg_bytes_per_frame": alg_bytes_stream // npic,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
@@ -211,7 +228,8 @@ def main():
     for row in syns:
         for y in row:
             y.close()
-    eng.close()
+    for e in engs:
+        e.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -783,19 +783,21 @@ __device__ __forceinline__ int intra_ang_neg(const int *cn, int sgn, int inv, in
 // above-right CTU, as far as any block's above-right neighbours go) and the column left of it.  CTUs of one
 // wave are independent: everything they read from outside was finished by earlier launches (inter
 // prediction, earlier waves).  Inside the CTU the blocks are processed level by level (blocks of a level do
-// not depend on each other), one wave per block, a workgroup barrier between levels.
+// not depend on each other), IT_WAVES blocks per round: first one wave per block gathers, substitutes and
+// smooths the block's reference samples, then all waves share the samples to predict, 64 at a time.
 //
 // Reference-sample array r[0..4n]: r[2n] is the corner, r[2n-1-j] the left column going down,
 // r[2n+1+i] the row above going right (TComPattern::initAdiPattern / fillReferenceSamples,
 // TLibCommon/TComPattern.cpp:213-602).  Availability comes per 4-luma-sample unit from the packer.
-#define IT_WAVES 4
+#define IT_WAVES 8 /* waves per workgroup (power of two) = blocks per round */
+#define IT_NTHR (IT_WAVES * 64)
 #define IT_YW 100 /* luma tile row: x = -1 .. 96 (97 used) */
 #define IT_CW 52  /* chroma tile row: x = -1 .. 48 (49 used) */
 #define IT_MAX_ITEMS 384
 #define IT_MAX_LEVELS 96
 
 template <typename pel_t>
-__global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, int wave_idx) {
+__global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s, int wave_idx) {
   __shared__ uint16_t tile_y[65 * IT_YW];
   __shared__ uint16_t tile_c[2][33 * IT_CW];
   __shared__ int16_t resi_y[64 * 64];
@@ -803,6 +805,7 @@ __global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, in
   __shared__ __attribute__((aligned(16))) IntraItem items_s[IT_MAX_ITEMS];
   __shared__ uint16_t lvlc_s[IT_MAX_LEVELS];
   __shared__ int ref_s[IT_WAVES][132], flt_s[IT_WAVES][132];
+  __shared__ unsigned blk_s[IT_WAVES][4];  // per block of the round: item words 0 and 1, filtered?, DC value
   const PicJob &J = jobs[blockIdx.y];
   if (wave_idx >= J.n_waves) return;
   const int first_ctu = J.wave_off[wave_idx];
@@ -822,10 +825,10 @@ __global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, in
     if (need_inside) {
       const pel_t *py = (const pel_t *)J.rec[0];
 #pragma unroll
-      for (int k = 0; k < 64 * VPR_Y / 256; k++) {
-        const int v = tid + k * 256, ty = v / VPR_Y, tx = (v % VPR_Y) * SPV;
+      for (int k = 0; k < (64 * VPR_Y + IT_NTHR - 1) / IT_NTHR; k++) {
+        const int v = tid + k * IT_NTHR, ty = v / VPR_Y, tx = (v % VPR_Y) * SPV;
         const int gx = ctux + tx, gy = ctuy + ty;
-        if (gx < s.w && gy < s.h) {
+        if (v < 64 * VPR_Y && gx < s.w && gy < s.h) {
           const uint4 q = *(const uint4 *)(py + (size_t)gy * s.stride_y + gx);
           const unsigned w[4] = {q.x, q.y, q.z, q.w};
           uint16_t *t = &tile_y[(ty + 1) * IT_YW + tx + 1];
@@ -836,8 +839,8 @@ __global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, in
       }
       constexpr int VPR_C = 32 * sizeof(pel_t) / 16;
 #pragma unroll
-      for (int k = 0; k < (2 * 32 * VPR_C + 255) / 256; k++) {
-        const int v = tid + k * 256;
+      for (int k = 0; k < (2 * 32 * VPR_C + IT_NTHR - 1) / IT_NTHR; k++) {
+        const int v = tid + k * IT_NTHR;
         if (v < 2 * 32 * VPR_C) {
           const int c = v / (32 * VPR_C), r = v % (32 * VPR_C), ty = r / VPR_C, tx = (r % VPR_C) * SPV;
           const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
@@ -871,200 +874,216 @@ __global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, in
           if (gx >= 0 && gy >= 0 && gx < s.cw) tile_c[c][i] = ((const pel_t *)J.rec[1 + c])[(size_t)gy * s.stride_c + gx];
         }
       }
-      if (tid >= 192) {
+      if (tid >= 192 && tid < 256) {
         const int c = (tid - 192) >> 5, j = (tid - 192) & 31;
         const int gx = (ctux >> 1) - 1, gy = (ctuy >> 1) + j;
         if (gx >= 0 && gy < s.ch) tile_c[c][(j + 1) * IT_CW] = ((const pel_t *)J.rec[1 + c])[(size_t)gy * s.stride_c + gx];
       }
     }
     // residual of the CTU's coded intra blocks (positions without one hold garbage and are never read)
-    for (int i = tid; i < 64 * 64 / 8; i += 256) {
+    for (int i = tid; i < 64 * 64 / 8; i += IT_NTHR) {
       const int ty = i >> 3, tx = (i & 7) * 8;
       const int gx = ctux + tx, gy = ctuy + ty;
       if (gx < s.w && gy < s.h) *(uint4 *)&resi_y[ty * 64 + tx] = *(const uint4 *)&J.resi[0][(size_t)gy * s.stride_y + gx];
     }
 #pragma unroll
     for (int c = 0; c < 2; c++)
-      for (int i = tid; i < 32 * 32 / 4; i += 256) {
+      for (int i = tid; i < 32 * 32 / 4; i += IT_NTHR) {
         const int ty = i >> 3, tx = (i & 7) * 4;
         const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
         if (gx < s.cw && gy < s.ch) *(uint2 *)&resi_c[c][ty * 32 + tx] = *(const uint2 *)&J.resi[1 + c][(size_t)gy * s.stride_c + gx];
       }
     const int nit = ci.n_items < IT_MAX_ITEMS ? ci.n_items : IT_MAX_ITEMS;
-    for (int i = tid; i < nit; i += 256) items_s[i] = J.intra[ci.item_start + i];
-    for (int i = tid; i < ci.n_lvl && i < IT_MAX_LEVELS; i += 256) lvlc_s[i] = J.lvl_counts[ci.lvl_start + i];
+    for (int i = tid; i < nit; i += IT_NTHR) items_s[i] = J.intra[ci.item_start + i];
+    for (int i = tid; i < ci.n_lvl && i < IT_MAX_LEVELS; i += IT_NTHR) lvlc_s[i] = J.lvl_counts[ci.lvl_start + i];
   }
   __syncthreads();
 
-  int *ref = ref_s[wv], *flt = flt_s[wv];
   int base = 0;
   const int n_lvl = ci.n_lvl < IT_MAX_LEVELS ? ci.n_lvl : IT_MAX_LEVELS;
   for (int lvl = 0; lvl < n_lvl; lvl++) {
     const int cnt = hr_uniform((int)lvlc_s[lvl]);
     for (int r0 = 0; r0 < cnt; r0 += IT_WAVES) {
-      const int idx = r0 + wv;
-      if (idx >= cnt || base + idx >= IT_MAX_ITEMS) continue;  // wave-uniform: the rest of the body has no workgroup barrier
-      // The block's description is the same in every lane: keep it in scalar registers.
-      const unsigned *iw = (const unsigned *)&items_s[base + idx];
-      const unsigned w0 = hr_uniform(iw[0]), w1 = hr_uniform(iw[1]), w2 = hr_uniform(iw[2]);
-      const int x0 = w0 & 0xffff, y0 = w0 >> 16;
-      const int log2n = w1 & 255, comp = (w1 >> 8) & 255, mode = (w1 >> 16) & 255, flags = w1 >> 24;
-      const int n = 1 << log2n;
-      const int sh = comp ? 1 : 0, lus = 2 - sh, us = 1 << lus, nu = n >> lus;
-      const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
-      uint16_t *tile = comp ? tile_c[comp - 1] : tile_y;
-      const int tw = comp ? IT_CW : IT_YW;
-      const int len = 4 * n + 1;
-      // position of the block inside the tile (tile index 0 = sample -1 of the CTU)
-      const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
+      const int nb = min(IT_WAVES, cnt - r0);  // blocks of this round
+      // ---- phase A: wave b builds the reference samples of block b ----
+      if (wv < nb) {
+        int *ref = ref_s[wv], *flt = flt_s[wv];
+        const bool in_range = base + r0 + wv < IT_MAX_ITEMS;
+        // The block's description is the same in every lane: keep it in scalar registers.
+        const unsigned *iw = (const unsigned *)&items_s[in_range ? base + r0 + wv : 0];
+        const unsigned w0 = hr_uniform(iw[0]), w1 = hr_uniform(iw[1]), w2 = hr_uniform(iw[2]);
+        const int x0 = w0 & 0xffff, y0 = w0 >> 16;
+        const int log2n = w1 & 255, comp = (w1 >> 8) & 255, mode = (w1 >> 16) & 255, flags = w1 >> 24;
+        const int n = 1 << log2n;
+        const int sh = comp ? 1 : 0, lus = 2 - sh, us = 1 << lus, nu = n >> lus;
+        const int bd = comp ? s.bd_c : s.bd_y;
+        const uint16_t *tile = comp ? tile_c[comp - 1] : tile_y;
+        const int tw = comp ? IT_CW : IT_YW;
+        const int len = 4 * n + 1;
+        // position of the block inside the tile (tile index 0 = sample -1 of the CTU)
+        const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
 
-      // availability of the 4*nu+1 units in scan order (bottom-left ... corner ... top-right)
-      const unsigned long long m = (unsigned long long)(hr_brev(w2 & 0xffff) >> (32 - 2 * nu)) |
-                                   ((flags & IN_CORNER) ? 1ull << (2 * nu) : 0ull) |
-                                   ((unsigned long long)((w2 >> 16) & ((1u << (2 * nu)) - 1)) << (2 * nu + 1));
+        // availability of the 4*nu+1 units in scan order (bottom-left ... corner ... top-right)
+        const unsigned long long m = (unsigned long long)(hr_brev(w2 & 0xffff) >> (32 - 2 * nu)) |
+                                     ((flags & IN_CORNER) ? 1ull << (2 * nu) : 0ull) |
+                                     ((unsigned long long)((w2 >> 16) & ((1u << (2 * nu)) - 1)) << (2 * nu + 1));
 
-      // 1. reference samples with unavailable units substituted (TLibCommon/TComPattern.cpp:424-435,546-588):
-      //    every lane works out which sample stands in for its position from the mask alone and reads it
-      //    straight from the tile.
-      if (m == 0) {
-        for (int i = lane; i < len; i += 64) ref[i] = 1 << (bd - 1);
-      } else {
-        const int ua = __ffsll((long long)m) - 1;  // first available unit: its first sample stands in for everything before it
-        const int first_src = ua < 2 * nu ? ua << lus : (ua == 2 * nu ? 2 * n : 2 * n + 1 + ((ua - 2 * nu - 1) << lus));
-        for (int i = lane; i < len; i += 64) {
-          const int u = i < 2 * n ? i >> lus : (i == 2 * n ? 2 * nu : 2 * nu + 1 + ((i - 2 * n - 1) >> lus));
-          int src = i;
-          if (!((m >> u) & 1)) {
-            const unsigned long long below = m & ((1ull << u) - 1);
-            if (below) {
-              const int ub = 63 - __clzll((long long)below);  // nearest available unit before this one: its last sample
-              src = ub < 2 * nu ? (ub << lus) + us - 1 : (ub == 2 * nu ? 2 * n : 2 * n + 1 + ((ub - 2 * nu - 1) << lus) + us - 1);
-            } else {
-              src = first_src;
+        // 1. reference samples with unavailable units substituted (TLibCommon/TComPattern.cpp:424-435,546-588):
+        //    every lane works out which sample stands in for its position from the mask alone and reads it
+        //    straight from the tile.
+        if (m == 0) {
+          for (int i = lane; i < len; i += 64) ref[i] = 1 << (bd - 1);
+        } else {
+          const int ua = __ffsll((long long)m) - 1;  // first available unit: its first sample stands in for everything before it
+          const int first_src = ua < 2 * nu ? ua << lus : (ua == 2 * nu ? 2 * n : 2 * n + 1 + ((ua - 2 * nu - 1) << lus));
+          for (int i = lane; i < len; i += 64) {
+            const int u = i < 2 * n ? i >> lus : (i == 2 * n ? 2 * nu : 2 * nu + 1 + ((i - 2 * n - 1) >> lus));
+            int src = i;
+            if (!((m >> u) & 1)) {
+              const unsigned long long below = m & ((1ull << u) - 1);
+              if (below) {
+                const int ub = 63 - __clzll((long long)below);  // nearest available unit before this one: its last sample
+                src = ub < 2 * nu ? (ub << lus) + us - 1 : (ub == 2 * nu ? 2 * n : 2 * n + 1 + ((ub - 2 * nu - 1) << lus) + us - 1);
+              } else {
+                src = first_src;
+              }
             }
+            // sample index -> tile coordinates: left column bottom-up, corner, row above left to right
+            const int sx = src <= 2 * n ? tx0 - 1 : tx0 + (src - 2 * n - 1);
+            const int sy = src < 2 * n ? ty0 + 2 * n - 1 - src : ty0 - 1;
+            ref[i] = tile[sy * tw + sx];
           }
-          // sample index -> tile coordinates: left column bottom-up, corner, row above left to right
-          const int sx = src <= 2 * n ? tx0 - 1 : tx0 + (src - 2 * n - 1);
-          const int sy = src < 2 * n ? ty0 + 2 * n - 1 - src : ty0 - 1;
-          ref[i] = tile[sy * tw + sx];
-        }
-      }
-      hr_wave_sync();
-      // 2. luma smoothing (TComPattern::getPredictorPtr :627-651 decides, :263-356 filters)
-      bool use_flt = false;
-      if (comp == 0 && mode != 1) {
-        const int thr = log2n == 2 ? 10 : log2n == 3 ? 7 : log2n == 4 ? 1 : 0;
-        use_flt = min(iabs(mode - 10), iabs(mode - 26)) > thr;
-      }
-      if (use_flt) {
-        bool strong = false;
-        if (s.strong_intra && n >= 32) {
-          const int thr = 1 << (bd - 5);
-          strong = iabs(ref[0] + ref[2 * n] - 2 * ref[n]) < thr && iabs(ref[2 * n] + ref[4 * n] - 2 * ref[3 * n]) < thr;
-        }
-        for (int i = lane; i < len; i += 64) {
-          int v;
-          if (i == 0 || i == len - 1) {
-            v = ref[i];
-          } else if (strong) {
-            // bilinear between the three corners; n = 32 so the shift is log2(2n) = 6
-            if (i < 2 * n)
-              v = ((2 * n - i) * ref[0] + i * ref[2 * n] + n) >> 6;
-            else if (i == 2 * n)
-              v = ref[i];
-            else
-              v = ((2 * n - (i - 2 * n)) * ref[2 * n] + (i - 2 * n) * ref[4 * n] + n) >> 6;
-          } else {
-            v = (ref[i - 1] + 2 * ref[i] + ref[i + 1] + 2) >> 2;
-          }
-          flt[i] = v;
         }
         hr_wave_sync();
-      }
-      const int *r = use_flt ? flt : ref;
-      const int *cn = r + 2 * n;  // cn[0] corner, cn[-1-j] left[j], cn[1+i] above[i]
-      // 3. prediction (TLibCommon/TComPrediction.cpp:183-390,691-763) + residual + store
-      const bool edge = comp == 0 && n <= 16;
-      const int16_t *resi = comp ? resi_c[comp - 1] : resi_y;
-      const int rw = comp ? 32 : 64;
-      const bool has_resi = (flags & IN_HAS_RESI) != 0;
-      const int16_t *resi0 = resi + (ty0 - 1) * rw + tx0 - 1;
-      uint16_t *tile0 = tile + ty0 * tw + tx0;
-      const int npx = n * n;
-#define INTRA_STORE_LOOP(EXPR)                                            \
-  for (int p0 = 0; p0 < npx; p0 += 256) {                                 \
-    int vv[4];                                                            \
-    _Pragma("unroll") for (int k = 0; k < 4; k++) {                       \
-      const int p = p0 + k * 64 + lane;                                   \
-      const int py = p >> log2n, px = p & (n - 1);                        \
-      int v = 0;                                                          \
-      if (p < npx) {                                                      \
-        v = (EXPR);                                                       \
-        if (has_resi) v += resi0[py * rw + px];                           \
-      }                                                                   \
-      vv[k] = v;                                                          \
-    }                                                                     \
-    _Pragma("unroll") for (int k = 0; k < 4; k++) {                       \
-      const int p = p0 + k * 64 + lane;                                   \
-      const int py = p >> log2n, px = p & (n - 1);                        \
-      if (p < npx) tile0[py * tw + px] = (uint16_t)clip3i(0, maxv, vv[k]); \
-    }                                                                     \
-  }
-      if (mode == 0) {  // planar
-        const int tr = cn[1 + n], bl = cn[-1 - n];
-        INTRA_STORE_LOOP(((cn[-1 - py] << log2n) + n + (px + 1) * (tr - cn[-1 - py]) + (cn[1 + px] << log2n) + (py + 1) * (bl - cn[1 + px])) >> (log2n + 1))
-      } else if (mode == 1) {  // DC: wave reduction over the 2n neighbours (TLibCommon/TComPrediction.cpp:122-160)
-        int part = 0;
-        if (lane < 2 * n) part = lane < n ? cn[1 + lane] : cn[-1 - (lane - n)];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
-        const int dcv = (part + n) >> (log2n + 1);
-        if (edge) {
-          INTRA_STORE_LOOP((px == 0 && py == 0) ? (cn[1] + cn[-1] + 2 * dcv + 2) >> 2
-                           : py == 0            ? (cn[1 + px] + 3 * dcv + 2) >> 2
-                           : px == 0            ? (cn[-1 - py] + 3 * dcv + 2) >> 2
-                                                : dcv)
-        } else {
-          INTRA_STORE_LOOP(dcv)
+        // 2. luma smoothing (TComPattern::getPredictorPtr :627-651 decides, :263-356 filters)
+        bool use_flt = false;
+        if (comp == 0 && mode != 1) {
+          const int thr = log2n == 2 ? 10 : log2n == 3 ? 7 : log2n == 4 ? 1 : 0;
+          use_flt = min(iabs(mode - 10), iabs(mode - 26)) > thr;
         }
-      } else {
-        // angular: vertical modes predict from the row above, horizontal modes are the same computation
-        // on the transposed block (main = left column): sgn flips the index direction
-        const bool hor = mode < 18;
-        const int a = hor ? -(mode - 10) : mode - 26;
-        const int aa = iabs(a);
-        const int at = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
-        const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
-        const int angle = a < 0 ? -at : at;
-        const int sgn = hor ? -1 : 1;  // MAIN(i) = cn[sgn * i], SIDE(i) = cn[-sgn * i]
+        int dcv = 0;
+        if (use_flt) {
+          bool strong = false;
+          if (s.strong_intra && n >= 32) {
+            const int thr = 1 << (bd - 5);
+            strong = iabs(ref[0] + ref[2 * n] - 2 * ref[n]) < thr && iabs(ref[2 * n] + ref[4 * n] - 2 * ref[3 * n]) < thr;
+          }
+          for (int i = lane; i < len; i += 64) {
+            int v;
+            if (i == 0 || i == len - 1) {
+              v = ref[i];
+            } else if (strong) {
+              // bilinear between the three corners; n = 32 so the shift is log2(2n) = 6
+              if (i < 2 * n)
+                v = ((2 * n - i) * ref[0] + i * ref[2 * n] + n) >> 6;
+              else if (i == 2 * n)
+                v = ref[i];
+              else
+                v = ((2 * n - (i - 2 * n)) * ref[2 * n] + (i - 2 * n) * ref[4 * n] + n) >> 6;
+            } else {
+              v = (ref[i - 1] + 2 * ref[i] + ref[i + 1] + 2) >> 2;
+            }
+            flt[i] = v;
+          }
+        } else if (mode == 1) {
+          // DC value: wave reduction over the 2n neighbours (TLibCommon/TComPrediction.cpp:122-160)
+          const int *cn = ref + 2 * n;
+          int part = 0;
+          if (lane < 2 * n) part = lane < n ? cn[1 + lane] : cn[-1 - (lane - n)];
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+          dcv = (part + n) >> (log2n + 1);
+        }
+        if (lane == 0) {
+          blk_s[wv][0] = w0;
+          blk_s[wv][1] = in_range ? w1 : 0u;  // log2n = 0 marks a slot without a block
+          blk_s[wv][2] = use_flt ? 1u : 0u;
+          blk_s[wv][3] = (unsigned)dcv;
+        }
+      }
+      __syncthreads();
+      // ---- phase B: prediction + residual + store (TLibCommon/TComPrediction.cpp:183-390,691-763), all waves
+      //      over all blocks of the round, 64 samples at a time; chunk c of block b goes to wave (b + c) % IT_WAVES
+      for (int b = 0; b < nb; b++) {
+        const unsigned w0 = hr_uniform(blk_s[b][0]), w1 = hr_uniform(blk_s[b][1]);
+        const int log2n = w1 & 255;
+        if (log2n == 0) continue;
+        const int n = 1 << log2n, npx = n * n;
+        const int c0 = (wv - b) & (IT_WAVES - 1);
+        if (c0 * 64 >= npx) continue;
+        const bool use_flt = hr_uniform(blk_s[b][2]) != 0;
+        const int dcv = (int)hr_uniform(blk_s[b][3]);
+        const int x0 = w0 & 0xffff, y0 = w0 >> 16;
+        const int comp = (w1 >> 8) & 255, mode = (w1 >> 16) & 255, flags = w1 >> 24;
+        const int sh = comp ? 1 : 0;
+        const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
+        uint16_t *tile = comp ? tile_c[comp - 1] : tile_y;
+        const int tw = comp ? IT_CW : IT_YW;
+        const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
+        const int *cn = (use_flt ? flt_s[b] : ref_s[b]) + 2 * n;  // cn[0] corner, cn[-1-j] left[j], cn[1+i] above[i]
+        const bool edge = comp == 0 && n <= 16;
+        const int16_t *resi = comp ? resi_c[comp - 1] : resi_y;
+        const int rw = comp ? 32 : 64;
+        const bool has_resi = (flags & IN_HAS_RESI) != 0;
+        const int16_t *resi0 = resi + (ty0 - 1) * rw + tx0 - 1;
+        uint16_t *tile0 = tile + ty0 * tw + tx0;
+#define INTRA_STORE_LOOP(EXPR)                                       \
+  for (int p = c0 * 64 + lane; p < npx; p += IT_WAVES * 64) {        \
+    const int py = p >> log2n, px = p & (n - 1);                     \
+    int v = (EXPR);                                                  \
+    if (has_resi) v += resi0[py * rw + px];                          \
+    tile0[py * tw + px] = (uint16_t)clip3i(0, maxv, v);              \
+  }
+        if (mode == 0) {  // planar
+          const int tr = cn[1 + n], bl = cn[-1 - n];
+          INTRA_STORE_LOOP(((cn[-1 - py] << log2n) + n + (px + 1) * (tr - cn[-1 - py]) + (cn[1 + px] << log2n) + (py + 1) * (bl - cn[1 + px])) >> (log2n + 1))
+        } else if (mode == 1) {  // DC
+          if (edge) {
+            INTRA_STORE_LOOP((px == 0 && py == 0) ? (cn[1] + cn[-1] + 2 * dcv + 2) >> 2
+                             : py == 0            ? (cn[1 + px] + 3 * dcv + 2) >> 2
+                             : px == 0            ? (cn[-1 - py] + 3 * dcv + 2) >> 2
+                                                  : dcv)
+          } else {
+            INTRA_STORE_LOOP(dcv)
+          }
+        } else {
+          // angular: vertical modes predict from the row above, horizontal modes are the same computation
+          // on the transposed block (main = left column): sgn flips the index direction
+          const bool hor = mode < 18;
+          const int a = hor ? -(mode - 10) : mode - 26;
+          const int aa = iabs(a);
+          const int at = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
+          const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
+          const int angle = a < 0 ? -at : at;
+          const int sgn = hor ? -1 : 1;  // MAIN(i) = cn[sgn * i], SIDE(i) = cn[-sgn * i]
 #define KK (hor ? px : py) /* index along the prediction direction */
 #define EE (hor ? py : px) /* index across it */
-        if (angle == 0) {
-          if (edge) {
-            const int side0 = cn[0];
-            INTRA_STORE_LOOP(EE == 0 ? clip3i(0, maxv, cn[sgn] + ((cn[-sgn * (KK + 1)] - side0) >> 1)) : cn[sgn * (EE + 1)])
+          if (angle == 0) {
+            if (edge) {
+              const int side0 = cn[0];
+              INTRA_STORE_LOOP(EE == 0 ? clip3i(0, maxv, cn[sgn] + ((cn[-sgn * (KK + 1)] - side0) >> 1)) : cn[sgn * (EE + 1)])
+            } else {
+              INTRA_STORE_LOOP(cn[sgn * (EE + 1)])
+            }
+          } else if (angle > 0) {
+            INTRA_STORE_LOOP(intra_ang_pos(cn, sgn, EE + 1 + (((KK + 1) * angle) >> 5), ((KK + 1) * angle) & 31))
           } else {
-            INTRA_STORE_LOOP(cn[sgn * (EE + 1)])
+            // negative indices address the side reference projected onto the main one
+            INTRA_STORE_LOOP(intra_ang_neg(cn, sgn, inv, EE + 1 + (((KK + 1) * angle) >> 5), ((KK + 1) * angle) & 31))
           }
-        } else if (angle > 0) {
-          INTRA_STORE_LOOP(intra_ang_pos(cn, sgn, EE + 1 + (((KK + 1) * angle) >> 5), ((KK + 1) * angle) & 31))
-        } else {
-          // negative indices address the side reference projected onto the main one
-          INTRA_STORE_LOOP(intra_ang_neg(cn, sgn, inv, EE + 1 + (((KK + 1) * angle) >> 5), ((KK + 1) * angle) & 31))
-        }
 #undef KK
 #undef EE
-      }
+        }
 #undef INTRA_STORE_LOOP
-      hr_wave_sync();  // the wave's next block reuses ref / flt
+      }
+      __syncthreads();  // the next round reads what this one wrote into the tile and reuses the block slots
     }
     base += cnt;
-    __syncthreads();  // the next level reads what this one wrote into the tile
   }
   // ---- write the CTU back (in P/B pictures the inter samples staged above go back unchanged) ----
   {
     pel_t *py = (pel_t *)J.rec[0];
-    for (int i = tid; i < 64 * 64 / 4; i += 256) {
+    for (int i = tid; i < 64 * 64 / 4; i += IT_NTHR) {
       const int ty = i >> 4, tx = (i & 15) * 4;
       const int gx = ctux + tx, gy = ctuy + ty;
       if (gx < s.w && gy < s.h) {
@@ -1081,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_intra(const PicJob *jobs, SeqInfo s, in
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       pel_t *pc = (pel_t *)J.rec[1 + c];
-      for (int i = tid; i < 32 * 32 / 4; i += 256) {
+      for (int i = tid; i < 32 * 32 / 4; i += IT_NTHR) {
         const int ty = i >> 3, tx = (i & 7) * 4;
         const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
         if (gx < s.cw && gy < s.ch) {
@@ -1375,7 +1394,7 @@ static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, 
     }
     case K_INTRA:
       // arg = CTU wave, arg2 = max number of CTUs in that wave over the batch
-      LAUNCH(k_intra<pel_t>, dim3(arg2, n), dim3(256), st, jobs, s, arg);
+      LAUNCH(k_intra<pel_t>, dim3(arg2, n), dim3(IT_NTHR), st, jobs, s, arg);
       break;
     case K_DEBLOCK_V:
       LAUNCH((k_deblock<pel_t, 0>), dim3(((s.w / 8) * s.uh + 255) / 256, n), dim3(256), st, jobs, s);

@@ -84,6 +84,15 @@ class Engine:
         ids = (C.c_int * n)(*dst_pic_ids)
         self._check(self.lib.hevcrecon_reconstruct_batch(self.ctx, n, hs, ids), "hevcrecon_reconstruct_batch")
 
+    def prepare_batch(self, syns, dst_pic_ids):
+        """Argument arrays of a reconstruct_batch call, built once for a batch that is submitted repeatedly."""
+        n = len(syns)
+        return (n, (C.c_void_p * n)(*[s.h for s in syns]), (C.c_int * n)(*dst_pic_ids))
+
+    def reconstruct_prepared(self, prepared):
+        n, hs, ids = prepared
+        self._check(self.lib.hevcrecon_reconstruct_batch(self.ctx, n, hs, ids), "hevcrecon_reconstruct_batch")
+
     def _planes(self):
         return [np.empty((self.h, self.w), np.int16), np.empty((self.h // 2, self.w // 2), np.int16),
                 np.empty((self.h // 2, self.w // 2), np.int16)]

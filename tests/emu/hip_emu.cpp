@@ -7,7 +7,7 @@ thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 namespace emu {
 
 namespace {
-const int kMaxThreads = 256;
+const int kMaxThreads = 1024;
 
 struct Pool {
   std::vector<std::thread> workers;
