@@ -38,16 +38,25 @@ def clone_for_stream(pic, s):
 
 
 def kernel_bytes(seq, stats_list, sao_flags):
-    """Algorithmic bytes per kernel class for a list of pictures: the terms of
-    S*b*(1 store + 2 deblock + 2 SAO) + MC reference reads + 2*coefficients + 16 per 4x4 record,
-    attributed to the kernel that moves them."""
+    """Algorithmic bytes per kernel for a list of pictures: the terms of
+    S*b*(1 store + 2 deblock + 2 SAO) + MC reference reads + 2*coefficients + 16 per 4x4 record (or 16 per
+    uniform-motion region), attributed to the kernel that moves them.  Luma + chroma = 1.5 bytes per luma
+    sample at 8 bits."""
     sp = seq.seq_params
     b = 2 if sp.bit_depth_luma > 8 else 1
     s_bytes = sp.width * sp.height * 3 // 2 * b
-    out = dict(k_inter=0, k_transform=0, k_intra=0, k_deblock_v=0, k_deblock_h=0, k_sao=0)
+    names = ["k_inter_tile64", "k_inter_tile32", "k_inter_tile16", "k_inter_blk", "k_transform", "k_intra", "k_deblock_v",
+             "k_deblock_h", "k_sao"]
+    out = dict.fromkeys(names, 0)
     for st, sao in zip(stats_list, sao_flags):
         n4, intra4 = st[8], st[9]
-        out["k_inter"] += (n4 - intra4) * 24 * b + st[7] * b + 16 * n4
+        tile_samples = tile_ref_samples = 0
+        for t, name in enumerate(names[:3]):
+            out[name] += (st[23 + t] + st[26 + t]) * 3 // 2 * b + 16 * st[16 + t]
+            tile_samples += st[23 + t]
+            tile_ref_samples += st[26 + t]
+        blk_units = (n4 - intra4) - tile_samples // 16
+        out["k_inter_blk"] += blk_units * 24 * b + (st[7] - tile_ref_samples * 3 // 2) * b + 16 * blk_units
         out["k_intra"] += intra4 * 24 * b
         out["k_transform"] += 2 * st[4]
         out["k_deblock_v"] += s_bytes
@@ -89,8 +98,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=8, help="independent streams per GPU")
-    ap.add_argument("--contexts", type=int, default=1, help="engine contexts (HIP streams) the streams of this GPU are spread over")
+    ap.add_argument("--streams", type=int, default=32, help="independent streams per GPU")
+    ap.add_argument("--contexts", type=int, default=4, help="engine contexts (HIP streams) the streams of this GPU are spread over")
     ap.add_argument("--fixture", default="randomaccess_main_1920x1080")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

@@ -10,7 +10,7 @@ import os
 
 MAX_REFS = 16
 PARTS_PER_CTU = 256
-NUM_KERNELS = 8
+NUM_KERNELS = 11
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhevcrecon.so")

@@ -140,6 +140,7 @@ struct PicJob {
 };
 
 // Kernel classes for the per-kernel timers (hevcrecon_profile_read).
-enum { K_INTER = 0, K_TRANSFORM, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_COPY, K_OTHER, K_COUNT };
+// K_INTER is also the launch kind of all four inter kernels; its timer slot holds the 64x64 tile kernel.
+enum { K_INTER = 0, K_TRANSFORM, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_COPY, K_OTHER, K_INTER_T32, K_INTER_T16, K_INTER_BLK, K_COUNT };
 
 #endif

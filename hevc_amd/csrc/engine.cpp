@@ -430,11 +430,25 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   return 0;
 }
 
-extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[16]) {
+extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[32]) {
   if (!s || !out) return 1;
   const PackedPicture &k = s->pk;
-  for (int i = 0; i < 16; i++) out[i] = 0;
+  for (int i = 0; i < 32; i++) out[i] = 0;
   for (int i = 0; i < 4; i++) out[i] = (int64_t)k.tu[i].size();
+  // motion compensation lists: regions per tile size, mixed 16x16 regions, reference blocks read per tile size
+  for (int t = 0; t < 3; t++) {
+    out[16 + t] = (int64_t)k.mc_tile[t].size();
+    const int ts = 64 >> t;
+    for (size_t i = 0; i < k.mc_tile[t].size(); i++) {
+      const McTile &m = k.mc_tile[t][i];
+      const int nref = (m.ref[0] >= 0) + (m.ref[1] >= 0);
+      const int64_t area = (int64_t)std::min<int>(ts, k.seq.w - m.x) * std::min<int>(ts, k.seq.h - m.y);
+      out[20 + t] += nref;
+      out[23 + t] += area;
+      out[26 + t] += area * nref;
+    }
+  }
+  out[19] = (int64_t)k.mc_blk.size();
   out[4] = (int64_t)k.coeff.size();
   out[5] = (int64_t)k.intra.size();
   out[6] = k.wave_off.empty() ? 0 : (int64_t)k.wave_off.size() - 1;
@@ -583,10 +597,14 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
   // ---- launches ----
   if (max_mct[0] > 0 || max_mct[1] > 0 || max_mct[2] > 0 || max_mcb > 0) {
     // arg = 0..2: uniform regions of 64, 32, 16 samples; 3: the mixed rest
-    Timed t(c, K_INTER, (max_mct[0] > 0) + (max_mct[1] > 0) + (max_mct[2] > 0) + (max_mcb > 0));
-    for (int t = 0; t < 3; t++)
-      if (max_mct[t] > 0) hr_launch(K_INTER, jd, n, s, c->stream, t, max_mct[t]);
-    if (max_mcb > 0) hr_launch(K_INTER, jd, n, s, c->stream, 3, max_mcb);
+    const int cls[4] = {K_INTER, K_INTER_T32, K_INTER_T16, K_INTER_BLK};
+    for (int t = 0; t < 4; t++) {
+      const int cnt = t < 3 ? max_mct[t] : max_mcb;
+      if (cnt > 0) {
+        Timed tm(c, cls[t], 1);
+        hr_launch(K_INTER, jd, n, s, c->stream, t, cnt);
+      }
+    }
   }
   {
     int nl = 0;
@@ -748,6 +766,7 @@ extern "C" int hevcrecon_profile_read(hevcrecon_ctx *c, double ms_out[HEVCRECON_
 }
 
 extern "C" const char *hevcrecon_kernel_name(int idx) {
-  static const char *names[K_COUNT] = {"k_inter", "k_transform", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao", "stage_copy", "other"};
+  static const char *names[K_COUNT] = {"k_inter_tile64", "k_transform", "k_intra",        "k_deblock_v",    "k_deblock_h", "k_sao",
+                                       "stage_copy",     "other",       "k_inter_tile32", "k_inter_tile16", "k_inter_blk"};
   return idx >= 0 && idx < K_COUNT ? names[idx] : "";
 }

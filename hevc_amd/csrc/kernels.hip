@@ -33,6 +33,7 @@ __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int hr_uniform(int v) { return v; }
 __device__ __forceinline__ unsigned hr_uniform(unsigned v) { return v; }
 __device__ __forceinline__ void hr_wave_sync() { emu::current_block().wave_barrier[emu::wave()].wait(); }
+__device__ __forceinline__ int hr_readlane(int v, int lane) { return __shfl(v, lane); }
 __device__ __forceinline__ unsigned hr_brev(unsigned v) {
   unsigned r = 0;
   for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i);
@@ -41,6 +42,8 @@ __device__ __forceinline__ unsigned hr_brev(unsigned v) {
 #else
 __device__ __forceinline__ int hr_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ unsigned hr_uniform(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+// value of lane `lane` (the same lane index in every lane of the wave), as a scalar
+__device__ __forceinline__ int hr_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ void hr_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -923,26 +926,38 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
         // position of the block inside the tile (tile index 0 = sample -1 of the CTU)
         const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
 
-        // availability of the 4*nu+1 units in scan order (bottom-left ... corner ... top-right)
-        const unsigned long long m = (unsigned long long)(hr_brev(w2 & 0xffff) >> (32 - 2 * nu)) |
-                                     ((flags & IN_CORNER) ? 1ull << (2 * nu) : 0ull) |
-                                     ((unsigned long long)((w2 >> 16) & ((1u << (2 * nu)) - 1)) << (2 * nu + 1));
+        // availability of the 4*nu+1 units in scan order (bottom-left ... corner ... top-right): units 0..31 in
+        // m, the 33rd unit of a 32x32 luma block (its last above-right unit) in m_top
+        const unsigned long long m64 = (unsigned long long)(hr_brev(w2 & 0xffff) >> (32 - 2 * nu)) |
+                                       ((flags & IN_CORNER) ? 1ull << (2 * nu) : 0ull) |
+                                       ((unsigned long long)((w2 >> 16) & ((1u << (2 * nu)) - 1)) << (2 * nu + 1));
+        const unsigned m = (unsigned)m64;
+        const bool m_top = (m64 >> 32) != 0;
 
         // 1. reference samples with unavailable units substituted (TLibCommon/TComPattern.cpp:424-435,546-588):
         //    every lane works out which sample stands in for its position from the mask alone and reads it
         //    straight from the tile.
-        if (m == 0) {
-          for (int i = lane; i < len; i += 64) ref[i] = 1 << (bd - 1);
+        // (three fixed slots of 64 samples, all tile reads issued before the first result is used: the round's
+        // length is set by dependent LDS round trips, not by instruction count)
+        if (m64 == 0) {
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+            if (lane + 64 * k < len) ref[lane + 64 * k] = 1 << (bd - 1);
         } else {
-          const int ua = __ffsll((long long)m) - 1;  // first available unit: its first sample stands in for everything before it
+          const int ua = __ffsll((long long)m64) - 1;  // first available unit: its first sample stands in for everything before it
           const int first_src = ua < 2 * nu ? ua << lus : (ua == 2 * nu ? 2 * n : 2 * n + 1 + ((ua - 2 * nu - 1) << lus));
-          for (int i = lane; i < len; i += 64) {
+          int off[3] = {0, 0, 0};
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            if (64 * k >= len) continue;  // wave-uniform
+            const int i = min(lane + 64 * k, len - 1);
             const int u = i < 2 * n ? i >> lus : (i == 2 * n ? 2 * nu : 2 * nu + 1 + ((i - 2 * n - 1) >> lus));
             int src = i;
-            if (!((m >> u) & 1)) {
-              const unsigned long long below = m & ((1ull << u) - 1);
+            const bool avail = u < 32 ? ((m >> u) & 1) != 0 : m_top;
+            if (!avail) {
+              const unsigned below = u < 32 ? m & ((1u << u) - 1) : m;
               if (below) {
-                const int ub = 63 - __clzll((long long)below);  // nearest available unit before this one: its last sample
+                const int ub = 31 - __clz((int)below);  // nearest available unit before this one: its last sample
                 src = ub < 2 * nu ? (ub << lus) + us - 1 : (ub == 2 * nu ? 2 * n : 2 * n + 1 + ((ub - 2 * nu - 1) << lus) + us - 1);
               } else {
                 src = first_src;
@@ -951,8 +966,14 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
             // sample index -> tile coordinates: left column bottom-up, corner, row above left to right
             const int sx = src <= 2 * n ? tx0 - 1 : tx0 + (src - 2 * n - 1);
             const int sy = src < 2 * n ? ty0 + 2 * n - 1 - src : ty0 - 1;
-            ref[i] = tile[sy * tw + sx];
+            off[k] = sy * tw + sx;
           }
+          int v[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) v[k] = tile[off[k]];
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+            if (lane + 64 * k < len) ref[lane + 64 * k] = v[k];
         }
         hr_wave_sync();
         // 2. luma smoothing (TComPattern::getPredictorPtr :627-651 decides, :263-356 filters)
@@ -963,25 +984,40 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
         }
         int dcv = 0;
         if (use_flt) {
+          // every read of the smoothing step is issued before the first is used
+          const int r0 = ref[0], rn = ref[n], r2n = ref[2 * n], r3n = ref[3 * n], r4n = ref[4 * n];
+          int a[3], b[3], c[3];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const int i = min(max(lane + 64 * k, 1), len - 2);  // in range for every lane, used or not
+            a[k] = ref[i - 1];
+            b[k] = ref[i];
+            c[k] = ref[i + 1];
+          }
           bool strong = false;
           if (s.strong_intra && n >= 32) {
             const int thr = 1 << (bd - 5);
-            strong = iabs(ref[0] + ref[2 * n] - 2 * ref[n]) < thr && iabs(ref[2 * n] + ref[4 * n] - 2 * ref[3 * n]) < thr;
+            strong = iabs(r0 + r2n - 2 * rn) < thr && iabs(r2n + r4n - 2 * r3n) < thr;
           }
-          for (int i = lane; i < len; i += 64) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            const int i = lane + 64 * k;
+            if (i >= len) continue;
             int v;
-            if (i == 0 || i == len - 1) {
-              v = ref[i];
+            if (i == 0) {
+              v = r0;
+            } else if (i == len - 1) {
+              v = r4n;
             } else if (strong) {
               // bilinear between the three corners; n = 32 so the shift is log2(2n) = 6
               if (i < 2 * n)
-                v = ((2 * n - i) * ref[0] + i * ref[2 * n] + n) >> 6;
+                v = ((2 * n - i) * r0 + i * r2n + n) >> 6;
               else if (i == 2 * n)
-                v = ref[i];
+                v = r2n;
               else
-                v = ((2 * n - (i - 2 * n)) * ref[2 * n] + (i - 2 * n) * ref[4 * n] + n) >> 6;
+                v = ((2 * n - (i - 2 * n)) * r2n + (i - 2 * n) * r4n + n) >> 6;
             } else {
-              v = (ref[i - 1] + 2 * ref[i] + ref[i + 1] + 2) >> 2;
+              v = (a[k] + 2 * b[k] + c[k] + 2) >> 2;
             }
             flt[i] = v;
           }
@@ -1003,16 +1039,32 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
       }
       __syncthreads();
       // ---- phase B: prediction + residual + store (TLibCommon/TComPrediction.cpp:183-390,691-763), all waves
-      //      over all blocks of the round, 64 samples at a time; chunk c of block b goes to wave (b + c) % IT_WAVES
-      for (int b = 0; b < nb; b++) {
-        const unsigned w0 = hr_uniform(blk_s[b][0]), w1 = hr_uniform(blk_s[b][1]);
+      //      over all blocks of the round, 64 samples at a time
+      // Lane b < nb fetches block b's slot; a block of npx samples is max(1, npx / 64) chunks, chunk g of the round
+      // belongs to wave g % IT_WAVES.  Every wave finds the blocks it has a chunk of with three ballots instead of
+      // walking the slots one dependent LDS read after the other.
+      unsigned my0 = 0, my1 = 0, my2 = 0, my3 = 0;
+      if (lane < nb) {
+        my0 = blk_s[lane][0];
+        my1 = blk_s[lane][1];
+        my2 = blk_s[lane][2];
+        my3 = blk_s[lane][3];
+      }
+      const int my_log2n = my1 & 255;
+      const unsigned long long below = (1ull << lane) - 1;
+      const int my_chunk0 = 16 * __popcll(__ballot(my_log2n == 5) & below) + 4 * __popcll(__ballot(my_log2n == 4) & below) +
+                            __popcll(__ballot(my_log2n == 2 || my_log2n == 3) & below);
+      const int my_nch = my_log2n == 5 ? 16 : my_log2n == 4 ? 4 : 1;
+      unsigned long long mine = __ballot(my_log2n != 0 && ((wv - my_chunk0) & (IT_WAVES - 1)) < my_nch);
+      while (mine) {
+        const int b = __ffsll((long long)mine) - 1;
+        mine &= mine - 1;
+        const unsigned w0 = (unsigned)hr_readlane((int)my0, b), w1 = (unsigned)hr_readlane((int)my1, b);
         const int log2n = w1 & 255;
-        if (log2n == 0) continue;
         const int n = 1 << log2n, npx = n * n;
-        const int c0 = (wv - b) & (IT_WAVES - 1);
-        if (c0 * 64 >= npx) continue;
-        const bool use_flt = hr_uniform(blk_s[b][2]) != 0;
-        const int dcv = (int)hr_uniform(blk_s[b][3]);
+        const int c0 = (wv - hr_readlane(my_chunk0, b)) & (IT_WAVES - 1);
+        const bool use_flt = hr_readlane((int)my2, b) != 0;
+        const int dcv = hr_readlane((int)my3, b);
         const int x0 = w0 & 0xffff, y0 = w0 >> 16;
         const int comp = (w1 >> 8) & 255, mode = (w1 >> 16) & 255, flags = w1 >> 24;
         const int sh = comp ? 1 : 0;

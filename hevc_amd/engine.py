@@ -36,7 +36,7 @@ class Syntax:
         return self
 
     def stats(self):
-        out = (C.c_int64 * 16)()
+        out = (C.c_int64 * 32)()
         self.lib.hevcrecon_syntax_stats(self.h, out)
         return list(out)
 

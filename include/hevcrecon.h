@@ -125,8 +125,12 @@ int hevcrecon_syntax_create_detached(const hevcrecon_seq_params *sp, hevcrecon_s
 /* Counters of the packed picture: out[0..3] coded transform blocks of size 4/8/16/32, [4] coded coefficients,
  * [5] intra prediction blocks, [6] intra CTU waves, [7] reference samples read by inter prediction,
  * [8] 4x4 records, [9] 4x4 records that are intra, [10] finished flag, [11] CTUs holding intra blocks,
- * [12] sum over those CTUs of their local dependency levels. */
-int hevcrecon_syntax_stats(const hevcrecon_syntax *syn, int64_t out[16]);
+ * [12] sum over those CTUs of their local dependency levels, [13] intra rounds on the critical path (slowest CTU
+ * of every wave), [14] intra rounds in total, [15] dependency levels on the critical path,
+ * [16..18] motion-compensation regions predicted as one block (64x64, 32x32, 16x16), [19] 16x16 regions predicted
+ * unit by unit, [20..22] reference blocks read by the regions of [16..18] (one per list in use),
+ * [23..25] luma samples those regions cover inside the picture, [26..28] the same weighted by lists in use. */
+int hevcrecon_syntax_stats(const hevcrecon_syntax *syn, int64_t out[32]);
 
 /* Start a new picture in `syn` (drops whatever it held).  Stands where TDecTop::xDecodeSlice
  * obtains the picture buffer for a first slice (TLibDecoder/TDecTop.cpp:358-376). */
@@ -180,7 +184,7 @@ int hevcrecon_synchronize(hevcrecon_ctx *ctx);
 
 /* Per-kernel GPU time, measured with HIP events on the context's stream while profiling is on.
  * Kernel indices: see hevcrecon_kernel_name(). */
-#define HEVCRECON_NUM_KERNELS 8
+#define HEVCRECON_NUM_KERNELS 11
 int hevcrecon_profile_enable(hevcrecon_ctx *ctx, int on);
 int hevcrecon_profile_read(hevcrecon_ctx *ctx, double ms_out[HEVCRECON_NUM_KERNELS],
                            int64_t launches_out[HEVCRECON_NUM_KERNELS]);

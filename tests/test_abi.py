@@ -39,4 +39,5 @@ def test_missing_library_fails_loudly(tmp_path):
 def test_kernel_names():
     lib = abi.load_library()
     names = [lib.hevcrecon_kernel_name(i).decode() for i in range(abi.NUM_KERNELS)]
-    assert names[:6] == ["k_inter", "k_transform", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao"]
+    assert names[:6] == ["k_inter_tile64", "k_transform", "k_intra", "k_deblock_v", "k_deblock_h", "k_sao"]
+    assert names[8:11] == ["k_inter_tile32", "k_inter_tile16", "k_inter_blk"]
