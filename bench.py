@@ -98,8 +98,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=32, help="independent streams per GPU")
-    ap.add_argument("--contexts", type=int, default=4, help="engine contexts (HIP streams) the streams of this GPU are spread over")
+    ap.add_argument("--streams", type=int, default=64, help="independent streams per GPU")
+    ap.add_argument("--contexts", type=int, default=1, help="engine contexts (HIP streams) the streams of this GPU are spread over")
     ap.add_argument("--fixture", default="randomaccess_main_1920x1080")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -204,6 +204,17 @@ def main():
     achieved = kb[dom] * S_prof / (dom_ms * 1e-3) / 1e9
     gpu_ms = sum(prof[k][0] for k in kb)
 
+    # HBM traffic of the dominant kernel: not measurable from inside the process; taken from the committed PMC
+    # passes (tools/pmc_passes.sh -> tools/pmc_traffic.py) when they were collected on this very configuration
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            tj = json.load(f)
+        if tj.get("streams") == S_prof and tj.get("fixture") == args.fixture and dom in tj.get("kernels", {}):
+            traffic = tj["kernels"][dom]["bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+
     frames_total = npic * S * args.steps * world
     value = frames_total / elapsed
     result = {
@@ -226,7 +237,8 @@ def main():
         "recon_alg_gbps_gpu_time": round(alg_bytes_stream * S_prof / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None,
         "alg_bytes_per_frame": alg_bytes_stream // npic,
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                     "alg_bytes_per_launch": int(kb[dom] * S_prof / max(dom_launches, 1)),
                      "launches_per_step": int(dom_launches), "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 3)},
         "kernels": kernels,
     }

@@ -457,7 +457,7 @@ __device__ __forceinline__ int hr_sdot4z(unsigned a, unsigned b) { return hr_sdo
 __device__ __forceinline__ int hr_sdot2z(unsigned a, unsigned b) { return hr_sdot2(a, b, 0); }
 
 template <int TS, int NTHR>
-__global__ __launch_bounds__(NTHR, (TS == 64 ? 5 : 8)) void k_inter_tile(const PicJob *jobs, SeqInfo s) {
+__global__ __launch_bounds__(NTHR, 8) void k_inter_tile(const PicJob *jobs, SeqInfo s) {
   constexpr int CS = TS / 2;                                     // chroma region size
   constexpr int NPY = (TS + 8) / 2, OY = TS / 8, TY = NPY * OY;  // luma: row pairs, 8-output groups per row, items
   constexpr int NPC = (CS + 4) / 2, OC = CS / 8, TC1 = NPC * OC, TC = 2 * TC1;  // chroma, both components
@@ -707,12 +707,13 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
   int acc[N];
 #pragma unroll
   for (int y = 0; y < N; y++) acc[y] = 0;
+  // the whole coefficient column is fetched before the first row is used (one trip to memory, not N)
+  int dq[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) dq[k] = live ? (int)coef[k * N + c] : 0;
+#pragma unroll
   for (int k = 0; k < N; k++) {
-    int d = 0;
-    if (live) {
-      int v = coef[k * N + c];
-      d = clip3i(-32768, 32767, (v * scale + add) >> shift);
-    }
+    const int d = clip3i(-32768, 32767, (dq[k] * scale + add) >> shift);
     if (tskip) tmp[t_local][k][c] = d;  // transform-skip blocks bypass both passes: keep the de-quantised block as it is
     const int dd = tskip ? 0 : d;
     if (!__any(dd != 0)) continue;  // wave-uniform
@@ -720,7 +721,7 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
     for (int y = 0; y < N; y++) {
       const int m = kT32[k * (32 / N)][y];
       const int md = (LOG2N == 2) ? kDst4[k][y & 3] : 0;
-      acc[y] += (dst4 ? md : m) * dd;
+      acc[y] += __mul24(dst4 ? md : m, dd);  // 8-bit x 16-bit: the 24-bit multiplier is exact and runs at full rate
     }
   }
   if (!tskip) {
@@ -733,20 +734,24 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
   int res[N];
 #pragma unroll
   for (int x = 0; x < N; x++) res[x] = 0;
+  int row[N];  // the lane's row of the intermediate, read from LDS in one go
+#pragma unroll
+  for (int k = 0; k < N; k++) row[k] = tmp[t_local][y][k];
+#pragma unroll
   for (int k = 0; k < N; k++) {
-    const int v = tskip ? 0 : tmp[t_local][y][k];
+    const int v = tskip ? 0 : row[k];
     if (!__any(v != 0)) continue;  // wave-uniform
 #pragma unroll
     for (int x = 0; x < N; x++) {
       const int m = kT32[k * (32 / N)][x];
       const int md = (LOG2N == 2) ? kDst4[k][x & 3] : 0;
-      res[x] += (dst4 ? md : m) * v;
+      res[x] += __mul24(dst4 ? md : m, v);
     }
   }
   if (tskip) {
     const int ts = 15 - bd - LOG2N;  // > 0 for every supported bit depth
 #pragma unroll
-    for (int x = 0; x < N; x++) res[x] = (tmp[t_local][y][x] + (1 << (ts - 1))) >> ts;
+    for (int x = 0; x < N; x++) res[x] = (row[x] + (1 << (ts - 1))) >> ts;
   } else {
     const int s2 = 12 - (bd - 8), r2 = 1 << (s2 - 1);
 #pragma unroll
@@ -770,13 +775,13 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
 // Angular prediction of one sample from main-reference index i0 (>= 0 for positive angles) and fraction df.
 __device__ __forceinline__ int intra_ang_pos(const int *cn, int sgn, int i0, int df) {
   const int a0 = cn[sgn * i0], a1 = cn[sgn * (i0 + 1)];
-  return df ? ((32 - df) * a0 + df * a1 + 16) >> 5 : a0;
+  return df ? (__mul24(32 - df, a0) + __mul24(df, a1) + 16) >> 5 : a0;
 }
 __device__ __forceinline__ int intra_ang_neg(const int *cn, int sgn, int inv, int i0, int df) {
   const int i1 = i0 + 1;
-  const int a0 = i0 >= 0 ? cn[sgn * i0] : cn[-sgn * ((128 - i0 * inv) >> 8)];
-  const int a1 = i1 >= 0 ? cn[sgn * i1] : cn[-sgn * ((128 - i1 * inv) >> 8)];
-  return df ? ((32 - df) * a0 + df * a1 + 16) >> 5 : a0;
+  const int a0 = i0 >= 0 ? cn[sgn * i0] : cn[-sgn * ((128 - __mul24(i0, inv)) >> 8)];
+  const int a1 = i1 >= 0 ? cn[sgn * i1] : cn[-sgn * ((128 - __mul24(i1, inv)) >> 8)];
+  return df ? (__mul24(32 - df, a0) + __mul24(df, a1) + 16) >> 5 : a0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1088,7 +1093,7 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
   }
         if (mode == 0) {  // planar
           const int tr = cn[1 + n], bl = cn[-1 - n];
-          INTRA_STORE_LOOP(((cn[-1 - py] << log2n) + n + (px + 1) * (tr - cn[-1 - py]) + (cn[1 + px] << log2n) + (py + 1) * (bl - cn[1 + px])) >> (log2n + 1))
+          INTRA_STORE_LOOP(((cn[-1 - py] << log2n) + n + __mul24(px + 1, tr - cn[-1 - py]) + (cn[1 + px] << log2n) + __mul24(py + 1, bl - cn[1 + px])) >> (log2n + 1))
         } else if (mode == 1) {  // DC
           if (edge) {
             INTRA_STORE_LOOP((px == 0 && py == 0) ? (cn[1] + cn[-1] + 2 * dcv + 2) >> 2
@@ -1118,10 +1123,10 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
               INTRA_STORE_LOOP(cn[sgn * (EE + 1)])
             }
           } else if (angle > 0) {
-            INTRA_STORE_LOOP(intra_ang_pos(cn, sgn, EE + 1 + (((KK + 1) * angle) >> 5), ((KK + 1) * angle) & 31))
+            INTRA_STORE_LOOP(intra_ang_pos(cn, sgn, EE + 1 + (__mul24(KK + 1, angle) >> 5), __mul24(KK + 1, angle) & 31))
           } else {
             // negative indices address the side reference projected onto the main one
-            INTRA_STORE_LOOP(intra_ang_neg(cn, sgn, inv, EE + 1 + (((KK + 1) * angle) >> 5), ((KK + 1) * angle) & 31))
+            INTRA_STORE_LOOP(intra_ang_neg(cn, sgn, inv, EE + 1 + (__mul24(KK + 1, angle) >> 5), __mul24(KK + 1, angle) & 31))
           }
 #undef KK
 #undef EE
@@ -1428,7 +1433,7 @@ static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, 
       // batch.  Tile grid.x is a multiple of 8, so that blockIdx.x & 7 is the XCD for every picture of the batch.
       if constexpr (sizeof(pel_t) == 1) {
         const dim3 g((arg2 + 7) / 8 * 8, n);
-        if (arg == 0) LAUNCH((k_inter_tile<64, 256>), g, dim3(256), st, jobs, s);
+        if (arg == 0) LAUNCH((k_inter_tile<64, 512>), g, dim3(512), st, jobs, s);
         if (arg == 1) LAUNCH((k_inter_tile<32, 256>), g, dim3(256), st, jobs, s);
         if (arg == 2) LAUNCH((k_inter_tile<16, 64>), g, dim3(64), st, jobs, s);
       }

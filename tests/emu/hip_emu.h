@@ -121,6 +121,7 @@ inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
 inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __mul24(int a, int b) { return a * b; }
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
 
