@@ -194,45 +194,69 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
 // to 64, sum(c_k * (p_k - 128)) = sum(c_k * p_k) - 8192, which IS the reference's 14-bit intermediate at
 // bit depth 8 (offset 8192, shift 0).  Rows whose vertical tap is zero are skipped when the vertical
 // fraction is zero.  Blocks whose window leaves the picture gather clamped bytes instead.
+struct __attribute__((packed)) HrBytes12 {
+  unsigned v[3];
+};
+struct __attribute__((packed)) HrBytes8 {
+  unsigned v[2];
+};
+
+// Window of a BW x BH block for an NT-tap filter: ROWS rows of NW dwords, samples biased by 128.
 template <int NT, int BW, int BH>
-__device__ __forceinline__ void interp_u8(const uint8_t *ref, int stride, int pw, int ph, int x0, int y0, unsigned tlo, unsigned thi,
-                                          const int *cy, bool v_identity, int out[BH][BW]) {
+__device__ __forceinline__ void interp_u8_load(const uint8_t *ref, int stride, int pw, int ph, int x0, int y0, bool v_identity,
+                                               unsigned w[BH + NT - 1][(BW + NT - 1 + 3) / 4]) {
   constexpr int HALF = NT / 2 - 1;
   constexpr int NPIX = BW + NT - 1;
   constexpr int NW = (NPIX + 3) / 4;
   constexpr int ROWS = BH + NT - 1;
   const int xs = x0 - HALF, ys = y0 - HALF;
   const bool inside = xs >= 0 && xs + NPIX - 1 < pw && ys >= 0 && ys + ROWS - 1 < ph;
-  const int a = xs & ~3, sh = xs & 3;
-  // All rows are fetched before any is used, so the block costs one trip to memory instead of one per row.
   // With a zero vertical fraction only the BH middle rows matter: the others re-read a middle row (same
-  // cache line, no extra traffic) and are skipped below.
-  unsigned w[ROWS][NW];
+  // cache line, no extra traffic) and are skipped by the filter.
   if (inside) {
-    unsigned d[ROWS][NW + 1];
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
       const int rr = v_identity ? clip3i(HALF, HALF + BH - 1, r) : r;
-      const unsigned *rp = (const unsigned *)(ref + (size_t)(ys + rr) * stride + a);
+      const uint8_t *rp = ref + (size_t)(ys + rr) * stride + xs;  // unaligned loads
+      if constexpr (NW == 3) {
+        const HrBytes12 q = *(const HrBytes12 *)rp;
 #pragma unroll
-      for (int k = 0; k <= NW; k++) d[r][k] = rp[k];
+        for (int k = 0; k < 3; k++) w[r][k] = q.v[k] ^ 0x80808080u;
+      } else {
+        const HrBytes8 q = *(const HrBytes8 *)rp;
+#pragma unroll
+        for (int k = 0; k < 2; k++) w[r][k] = q.v[k] ^ 0x80808080u;
+      }
     }
-#pragma unroll
-    for (int r = 0; r < ROWS; r++)
-#pragma unroll
-      for (int k = 0; k < NW; k++) w[r][k] = hr_alignbyte(d[r][k + 1], d[r][k], sh) ^ 0x80808080u;
   } else {
+    int xb = xs;  // (see tile_row_load: keeps the clamping arithmetic of this rare path inside the branch)
+#ifndef HEVCRECON_EMULATE
+    asm volatile("" : "+v"(xb));
+#endif
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
       const uint8_t *row = ref + (size_t)clip3i(0, ph - 1, ys + r) * stride;
 #pragma unroll
       for (int k = 0; k < NW; k++) w[r][k] = 0;
 #pragma unroll
-      for (int i = 0; i < NPIX; i++) w[r][i >> 2] |= (unsigned)row[clip3i(0, pw - 1, xs + i)] << (8 * (i & 3));
+      for (int i = 0; i < NPIX; i++) w[r][i >> 2] |= (unsigned)row[clip3i(0, pw - 1, xb + i)] << (8 * (i & 3));
 #pragma unroll
       for (int k = 0; k < NW; k++) w[r][k] ^= 0x80808080u;
     }
   }
+}
+
+// Same arithmetic as interp_block for 8-bit samples, organised for the hardware: samples biased to signed
+// bytes (x ^ 0x80 = x - 128), the horizontal filter is two 4-way byte dot products.  Because the taps sum
+// to 64, sum(c_k * (p_k - 128)) = sum(c_k * p_k) - 8192, which IS the reference's 14-bit intermediate at
+// bit depth 8 (offset 8192, shift 0).  Rows whose vertical tap is zero are skipped when the vertical
+// fraction is zero.
+template <int NT, int BW, int BH>
+__device__ __forceinline__ void interp_u8_filter(const unsigned w[BH + NT - 1][(BW + NT - 1 + 3) / 4], unsigned tlo, unsigned thi,
+                                                 const int *cy, bool v_identity, int out[BH][BW]) {
+  constexpr int HALF = NT / 2 - 1;
+  constexpr int NW = (BW + NT - 1 + 3) / 4;
+  constexpr int ROWS = BH + NT - 1;
   int acc[BH][BW];
 #pragma unroll
   for (int j = 0; j < BH; j++)
@@ -252,7 +276,7 @@ __device__ __forceinline__ void interp_u8(const uint8_t *ref, int stride, int pw
 #pragma unroll
       for (int j = 0; j < BH; j++) {
         const int k = r - j;
-        if (k >= 0 && k < NT) acc[j][i] += cy[k] * h;
+        if (k >= 0 && k < NT) acc[j][i] += __mul24(cy[k], h);
       }
     }
   }
@@ -290,42 +314,82 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int i = 0; i < 2; i++) lc[c][j][i] = 0;
-  for (int l = 0; l < 2; l++) {
-    if (!(l ? use1 : use0)) continue;
-    const int ri = p.ref_idx[l];
-    const int mvx = min(hmax, max(hmin, (int)p.mv[l][0])), mvy = min(vmax, max(vmin, (int)p.mv[l][1]));
-    {
-      int tx[8], ty[8], o[4][4];
-      luma_taps(mvx & 3, tx);
-      luma_taps(mvy & 3, ty);
-      if constexpr (sizeof(pel_t) == 1)
-        interp_u8<8, 4, 4>((const uint8_t *)J.ref[l][ri][0], s.stride_y, s.w, s.h, x + (mvx >> 2), y + (mvy >> 2),
-                           pack4(tx[0], tx[1], tx[2], tx[3]), pack4(tx[4], tx[5], tx[6], tx[7]), ty, (mvy & 3) == 0, o);
-      else
+  if constexpr (sizeof(pel_t) == 1) {
+    // 8-bit pictures: the windows of both lists and all three planes are fetched before anything is filtered,
+    // so a lane pays one trip to memory instead of six dependent ones
+    unsigned wy[2][11][3], wc[2][2][5][2];
+    int mvx[2], mvy[2];
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      if (!(l ? use1 : use0)) continue;
+      const int ri = p.ref_idx[l];
+      mvx[l] = min(hmax, max(hmin, (int)p.mv[l][0]));
+      mvy[l] = min(vmax, max(vmin, (int)p.mv[l][1]));
+      interp_u8_load<8, 4, 4>((const uint8_t *)J.ref[l][ri][0], s.stride_y, s.w, s.h, x + (mvx[l] >> 2), y + (mvy[l] >> 2),
+                              (mvy[l] & 3) == 0, wy[l]);
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+        interp_u8_load<4, 2, 2>((const uint8_t *)J.ref[l][ri][1 + c], s.stride_c, s.cw, s.ch, (x >> 1) + (mvx[l] >> 3),
+                                (y >> 1) + (mvy[l] >> 3), (mvy[l] & 7) == 0, wc[l][c]);
+    }
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      if (!(l ? use1 : use0)) continue;
+      {
+        int tx[8], ty[8], o[4][4];
+        luma_taps(mvx[l] & 3, tx);
+        luma_taps(mvy[l] & 3, ty);
+        interp_u8_filter<8, 4, 4>(wy[l], pack4(tx[0], tx[1], tx[2], tx[3]), pack4(tx[4], tx[5], tx[6], tx[7]), ty, (mvy[l] & 3) == 0, o);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) ly[j][i] += o[j][i];
+      }
+      {
+        int tx[4], ty[4];
+        chroma_taps(mvx[l] & 7, tx);
+        chroma_taps(mvy[l] & 7, ty);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+          int o[2][2];
+          interp_u8_filter<4, 2, 2>(wc[l][c], pack4(tx[0], tx[1], tx[2], tx[3]), 0u, ty, (mvy[l] & 7) == 0, o);
+#pragma unroll
+          for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 2; i++) lc[c][j][i] += o[j][i];
+        }
+      }
+    }
+  } else {
+    for (int l = 0; l < 2; l++) {
+      if (!(l ? use1 : use0)) continue;
+      const int ri = p.ref_idx[l];
+      const int mvx = min(hmax, max(hmin, (int)p.mv[l][0])), mvy = min(vmax, max(vmin, (int)p.mv[l][1]));
+      {
+        int tx[8], ty[8], o[4][4];
+        luma_taps(mvx & 3, tx);
+        luma_taps(mvy & 3, ty);
         interp_block<pel_t, 8, 4, 4>(plane_c<pel_t>(J.ref[l][ri][0]), s.stride_y, s.w, s.h, x + (mvx >> 2), y + (mvy >> 2), tx, ty,
                                      s.bd_y, o);
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) ly[j][i] += o[j][i];
-    }
-    {
-      int tx[4], ty[4];
-      chroma_taps(mvx & 7, tx);
-      chroma_taps(mvy & 7, ty);
+          for (int i = 0; i < 4; i++) ly[j][i] += o[j][i];
+      }
+      {
+        int tx[4], ty[4];
+        chroma_taps(mvx & 7, tx);
+        chroma_taps(mvy & 7, ty);
 #pragma unroll
-      for (int c = 0; c < 2; c++) {
-        int o[2][2];
-        if constexpr (sizeof(pel_t) == 1)
-          interp_u8<4, 2, 2>((const uint8_t *)J.ref[l][ri][1 + c], s.stride_c, s.cw, s.ch, (x >> 1) + (mvx >> 3), (y >> 1) + (mvy >> 3),
-                             pack4(tx[0], tx[1], tx[2], tx[3]), 0u, ty, (mvy & 7) == 0, o);
-        else
+        for (int c = 0; c < 2; c++) {
+          int o[2][2];
           interp_block<pel_t, 4, 2, 2>(plane_c<pel_t>(J.ref[l][ri][1 + c]), s.stride_c, s.cw, s.ch, (x >> 1) + (mvx >> 3),
                                        (y >> 1) + (mvy >> 3), tx, ty, s.bd_c, o);
 #pragma unroll
-        for (int j = 0; j < 2; j++)
+          for (int j = 0; j < 2; j++)
 #pragma unroll
-          for (int i = 0; i < 2; i++) lc[c][j][i] += o[j][i];
+            for (int i = 0; i < 2; i++) lc[c][j][i] += o[j][i];
+        }
       }
     }
   }
@@ -463,7 +527,7 @@ __global__ __launch_bounds__(NTHR, 8) void k_inter_tile(const PicJob *jobs, SeqI
   constexpr int NPC = (CS + 4) / 2, OC = CS / 8, TC1 = NPC * OC, TC = 2 * TC1;  // chroma, both components
   // With SEG the chroma items of a list start at a multiple of 64, so that a wave never mixes luma and chroma
   // and everything that depends on the class stays in scalar registers.
-  constexpr bool SEG = TS >= 32;
+  constexpr bool SEG = TS >= 64;
   constexpr int LYP = SEG ? (TY + 63) / 64 * 64 : TY;
   constexpr int HIT = (LYP + TC + NTHR - 1) / NTHR;  // H items per lane and list
   constexpr int LVL = TS == 64 ? 0 : TS == 32 ? 1 : 2;
@@ -1434,7 +1498,7 @@ static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, 
       if constexpr (sizeof(pel_t) == 1) {
         const dim3 g((arg2 + 7) / 8 * 8, n);
         if (arg == 0) LAUNCH((k_inter_tile<64, 512>), g, dim3(512), st, jobs, s);
-        if (arg == 1) LAUNCH((k_inter_tile<32, 256>), g, dim3(256), st, jobs, s);
+        if (arg == 1) LAUNCH((k_inter_tile<32, 128>), g, dim3(128), st, jobs, s);
         if (arg == 2) LAUNCH((k_inter_tile<16, 64>), g, dim3(64), st, jobs, s);
       }
       if (arg == 3) LAUNCH(k_inter_blk<pel_t>, dim3((arg2 + 15) / 16, n), dim3(256), st, jobs, s);
