@@ -5,13 +5,15 @@
 // translation: the reference walks CTU by CTU on one thread, here every kind of work runs over the
 // whole picture (and over a batch of pictures, blockIdx.y) at once:
 //
-//   k_inter      one lane per 4x4 luma block (+ its 2x2 chroma blocks): motion compensation straight
-//                from the per-4x4 motion records, no PU list
+//   k_inter_tile one workgroup per 64x64 / 32x32 / 16x16 region of uniform motion (8-bit pictures): separable
+//                interpolation through LDS, byte and 16-bit dot products
+//   k_inter_blk  one lane per 4x4 luma block (+ its 2x2 chroma blocks) of the regions with mixed motion:
+//                motion compensation straight from the per-4x4 motion records
 //   k_transform  one lane per column/row of a transform block: de-quantisation + 2-D inverse
 //                transform, result added to the picture (inter) or kept as residual (intra)
 //   k_intra      one workgroup per CTU (CTU staged in LDS, blocks level by level inside), one launch per CTU wave
 //   k_deblock    one lane per 4-sample edge segment; vertical edges, then horizontal edges
-//   k_sao        one lane per 4 samples, out of place (deblocked picture -> final picture)
+//   k_sao        one lane per 16 samples, out of place (deblocked picture -> final picture)
 #ifdef HEVCRECON_EMULATE
 #include "hip_emu.h"
 #else

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Collects the round's evidence on the GPU machine (run from the repository root through gpurun):
+#   gpurun_out/final/kernel_stats.csv   rocprofv3 --kernel-trace --stats of the default bench.py command
+#   gpurun_out/final/pmc_summary.txt    per-kernel averages of the PMC passes (tools/pmc_passes.sh)
+#   gpurun_out/final/hbm_traffic.json   HBM bytes per launch from FETCH_SIZE / WRITE_SIZE
+#   gpurun_out/final/bench.json         the bench.py line (run without the profiler)
+# Copy them into profiles/ afterwards.
+set -e
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/final
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu-baseline > $O/bench_profiled.log 2>&1
+cp $O/trace/*/*kernel_stats.csv $O/kernel_stats.csv
+rm -rf $O/trace
+cd $R
+bash tools/pmc_passes.sh 64
+python3 tools/pmc_summary.py gpurun_out/pmc > $O/pmc_summary.txt
+python3 tools/pmc_traffic.py gpurun_out/pmc 64 randomaccess_main_1920x1080 > $O/hbm_traffic.json
+rm -rf gpurun_out/pmc/p*/
+timeout -k 10 500 python3 -u bench.py > $O/bench.log 2>&1
+tail -1 $O/bench.log > $O/bench.json

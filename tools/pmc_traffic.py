@@ -20,15 +20,28 @@ for p in ("p3", "p4"):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k][r["Counter_Name"]].add(r["Dispatch_Id"])
-names = {"k_inter_tile<64, 256>": "k_inter_tile64", "k_inter_tile<32, 256>": "k_inter_tile32", "k_inter_tile<16, 64>": "k_inter_tile16",
-         "k_inter_blk<unsigned char>": "k_inter_blk", "k_intra<unsigned char>": "k_intra", "k_sao<unsigned char>": "k_sao",
-         "k_deblock<unsigned char, 0>": "k_deblock_v", "k_deblock<unsigned char, 1>": "k_deblock_h"}
+import re
+
+
+def short_name(k):
+    m = re.match(r"k_inter_tile<(\d+),", k)
+    if m:
+        return "k_inter_tile" + m.group(1)
+    m = re.match(r"k_deblock<[^,]*, (\d)>", k)
+    if m:
+        return "k_deblock_v" if m.group(1) == "0" else "k_deblock_h"
+    m = re.match(r"k_transform<[^,]*, (\d)>", k)
+    if m:
+        return "k_transform%d" % (1 << int(m.group(1)))
+    return k.split("<")[0]
+
+
 out = {"streams": streams, "fixture": fixture, "unit": "bytes", "formula": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch", "kernels": {}}
 for k, v in acc.items():
-    if k not in names or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+    if not k.startswith("k_") or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue
     f = v["FETCH_SIZE"] / len(disp[k]["FETCH_SIZE"]) * 1024
     w = v["WRITE_SIZE"] / len(disp[k]["WRITE_SIZE"]) * 1024
-    out["kernels"][names[k]] = {"fetch_size_bytes_raw": int(f), "write_size_bytes": int(w), "bytes_per_launch": int(2 * f + w)}
+    out["kernels"][short_name(k)] = {"fetch_size_bytes_raw": int(f), "write_size_bytes": int(w), "bytes_per_launch": int(2 * f + w)}
 json.dump(out, sys.stdout, indent=1)
 print()
