@@ -5,7 +5,7 @@
 // translation: the reference walks CTU by CTU on one thread, here every kind of work runs over the
 // whole picture (and over a batch of pictures, blockIdx.y) at once:
 //
-//   k_inter_tile one workgroup per 64x64 / 32x32 / 16x16 region of uniform motion (8-bit pictures): separable
+//   k_inter_tile one workgroup per 64x64 / 32x32 / 16x16 region of uniform motion: separable
 //                interpolation through LDS, byte and 16-bit dot products
 //   k_inter_blk  one lane per 4x4 luma block (+ its 2x2 chroma blocks) of the regions with mixed motion:
 //                motion compensation straight from the per-4x4 motion records
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256) void k_inter_blk(const PicJob *jobs, SeqInfo s
   inter_unit<pel_t>(J, s, ux, uy);
 }
 
-// ---- k_inter_tile: regions with uniform motion, 8-bit pictures -----------------------------------------
+// ---- k_inter_tile: regions with uniform motion -----------------------------------------------------------
 // One workgroup predicts a TS x TS luma region (TS = 64, 32, 16) and its two chroma regions as single blocks.
 //   phase H  work items of two window rows x eight outputs: the lane fetches 16 bytes of each row straight
 //            from the reference picture (unaligned loads; the lanes of a row are contiguous, so they
@@ -469,12 +469,12 @@ __device__ __forceinline__ int hr_sdot2(unsigned a, unsigned b, int c) {
 // optimiser on purpose: hipcc (ROCm 7.2) otherwise fuses "shift, clamp to 0..255, pack two bytes" into
 // v_ashr_pk_u8_i32 and then ORs the other two bytes into the upper half of its result register, which that
 // instruction does not clear on gfx950 (the upper bytes of a negative input came out as 0xFF).
-__device__ __forceinline__ int tile_px(int v, int off, int sh) {
+__device__ __forceinline__ int tile_px(int v, int off, int sh, int maxv = 255) {
   int x = (v + off) >> sh;
 #ifndef HEVCRECON_EMULATE
   asm volatile("" : "+v"(x));
 #endif
-  return clip3i(0, 255, x);
+  return clip3i(0, maxv, x);
 }
 __device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
 
@@ -502,6 +502,24 @@ __device__ __forceinline__ void tile_row_load(const uint8_t *row, int x0, int pw
   }
 }
 
+// 16 samples (two 16-byte loads) of a row of a 16-bit picture, two samples per dword
+__device__ __forceinline__ void tile_row_load(const uint16_t *row, int x0, int pw, bool fast, unsigned w[8]) {
+  if (fast) {
+    const HrBytes16 q0 = *(const HrBytes16 *)(row + x0), q1 = *(const HrBytes16 *)(row + x0 + 8);
+#pragma unroll
+    for (int k = 0; k < 4; k++) w[k] = q0.v[k], w[4 + k] = q1.v[k];
+  } else {
+    int xb = x0;
+#ifndef HEVCRECON_EMULATE
+    asm volatile("" : "+v"(xb));
+#endif
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i >> 1] |= (unsigned)row[clip3i(0, pw - 1, xb + i)] << (16 * (i & 1));
+  }
+}
+
 // Packed tap tables (TLibCommon/TComInterpolationFilter.cpp:55-73), read with wave-uniform indices:
 // four signed bytes per dword for the horizontal byte dot products, 16-bit pairs for the vertical ones
 // ("even": taps (0,1)(2,3)...; "odd": the same taps shifted by one row, (-,0)(1,2)...(7,-)).
@@ -522,8 +540,10 @@ __constant__ unsigned kChromaTab[8][8] = {HR_C4(0, 64, 0, 0),    HR_C4(-2, 58, 1
 __device__ __forceinline__ int hr_sdot4z(unsigned a, unsigned b) { return hr_sdot4(a, b, 0); }
 __device__ __forceinline__ int hr_sdot2z(unsigned a, unsigned b) { return hr_sdot2(a, b, 0); }
 
-template <int TS, int NTHR>
-__global__ __launch_bounds__(NTHR, 8) void k_inter_tile(const PicJob *jobs, SeqInfo s) {
+template <typename pel_t, int TS, int NTHR>
+__global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_tile(const PicJob *jobs, SeqInfo s) {
+  constexpr bool W16 = sizeof(pel_t) == 2;  // 16-bit planes: 16-bit dot products in the horizontal pass too
+  constexpr int WD = W16 ? 8 : 4;           // dwords fetched per window row and work item (16 samples)
   constexpr int CS = TS / 2;                                     // chroma region size
   constexpr int NPY = (TS + 8) / 2, OY = TS / 8, TY = NPY * OY;  // luma: row pairs, 8-output groups per row, items
   constexpr int NPC = (CS + 4) / 2, OC = CS / 8, TC1 = NPC * OC, TC = 2 * TC1;  // chroma, both components
@@ -558,7 +578,7 @@ __global__ __launch_bounds__(NTHR, 8) void k_inter_tile(const PicJob *jobs, SeqI
   const int p = chroma ? kk / OC : kk / OY, o = chroma ? kk % OC : kk % OY;                      \
   const bool live = t.ref[l] >= 0 && k < (chroma ? TC : TY) &&                                   \
                     !(chroma ? vid_c[l] && p > CS / 2 : vid_y[l] && (p < 1 || p > TS / 2 + 1));
-  unsigned w[2][HIT][2][4];
+  unsigned w[2][HIT][2][WD];
 #pragma unroll
   for (int l = 0; l < 2; l++) {
     const int ri = t.ref[l] >= 0 ? t.ref[l] : 0;
@@ -570,7 +590,7 @@ __global__ __launch_bounds__(NTHR, 8) void k_inter_tile(const PicJob *jobs, SeqI
     for (int it = 0; it < HIT; it++) {
       MT_DECODE
       if (live) {
-        const uint8_t *base = (const uint8_t *)(chroma ? (comp ? J.ref[l][ri][2] : J.ref[l][ri][1]) : J.ref[l][ri][0]);
+        const pel_t *base = (const pel_t *)(chroma ? (comp ? J.ref[l][ri][2] : J.ref[l][ri][1]) : J.ref[l][ri][0]);
         const int stride = chroma ? s.stride_c : s.stride_y, pw = chroma ? s.cw : s.w, ph = chroma ? s.ch : s.h;
         const int x0 = (chroma ? cwx0 : wx0) + 8 * o, y0 = chroma ? cwy0 : wy0;
         const int last = chroma ? CS + 2 : TS + 6;
@@ -592,7 +612,32 @@ __global__ __launch_bounds__(NTHR, 8) void k_inter_tile(const PicJob *jobs, SeqI
       MT_DECODE
       if (live) {
         int h[2][8];
-        if (!chroma) {
+        if constexpr (W16) {
+          // 16-bit samples: (sum - (8192 << s1)) >> s1 with s1 = bit depth - 8; even outputs use the tap pairs
+          // (0,1)(2,3).., odd outputs the pairs shifted by one sample, so no sample ever has to be re-aligned
+          const int s1 = (chroma ? s.bd_c : s.bd_y) - 8, init = -(8192 << s1);
+#pragma unroll
+          for (int rr = 0; rr < 2; rr++) {
+            const unsigned *x = w[l][it][rr];
+            if (!chroma) {
+#pragma unroll
+              for (int i = 0; i < 8; i++) {
+                const int d = i >> 1;
+                const int sum = (i & 1) ? hr_sdot2(x[d + 4], lt[10], hr_sdot2(x[d + 3], lt[9], hr_sdot2(x[d + 2], lt[8], hr_sdot2(x[d + 1], lt[7], hr_sdot2(x[d], lt[6], init)))))
+                                        : hr_sdot2(x[d + 3], lt[5], hr_sdot2(x[d + 2], lt[4], hr_sdot2(x[d + 1], lt[3], hr_sdot2(x[d], lt[2], init))));
+                h[rr][i] = sum >> s1;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 8; i++) {
+                const int d = i >> 1;
+                const int sum = (i & 1) ? hr_sdot2(x[d + 2], ct[5], hr_sdot2(x[d + 1], ct[4], hr_sdot2(x[d], ct[3], init)))
+                                        : hr_sdot2(x[d + 1], ct[2], hr_sdot2(x[d], ct[1], init));
+                h[rr][i] = sum >> s1;
+              }
+            }
+          }
+        } else if (!chroma) {
 #pragma unroll
           for (int rr = 0; rr < 2; rr++) {
             unsigned x[4], a[12];
@@ -603,9 +648,6 @@ __global__ __launch_bounds__(NTHR, 8) void k_inter_tile(const PicJob *jobs, SeqI
 #pragma unroll
             for (int i = 0; i < 8; i++) h[rr][i] = hr_sdot4(a[i + 4], c_hi, hr_sdot4z(a[i], c_lo));
           }
-          uint4 *dst = (uint4 *)&P_y[l][p * TS + 8 * o];
-          dst[0] = make_uint4(pack16(h[0][0], h[1][0]), pack16(h[0][1], h[1][1]), pack16(h[0][2], h[1][2]), pack16(h[0][3], h[1][3]));
-          dst[1] = make_uint4(pack16(h[0][4], h[1][4]), pack16(h[0][5], h[1][5]), pack16(h[0][6], h[1][6]), pack16(h[0][7], h[1][7]));
         } else {
 #pragma unroll
           for (int rr = 0; rr < 2; rr++) {
@@ -615,10 +657,10 @@ __global__ __launch_bounds__(NTHR, 8) void k_inter_tile(const PicJob *jobs, SeqI
 #pragma unroll
             for (int i = 0; i < 8; i++) h[rr][i] = hr_sdot4z((i & 3) ? hr_alignbyte(x[(i >> 2) + 1], x[i >> 2], i & 3) : x[i >> 2], c4);
           }
-          uint4 *dst = (uint4 *)&P_c[l][0][comp * (NPC * CS) + p * CS + 8 * o];
-          dst[0] = make_uint4(pack16(h[0][0], h[1][0]), pack16(h[0][1], h[1][1]), pack16(h[0][2], h[1][2]), pack16(h[0][3], h[1][3]));
-          dst[1] = make_uint4(pack16(h[0][4], h[1][4]), pack16(h[0][5], h[1][5]), pack16(h[0][6], h[1][6]), pack16(h[0][7], h[1][7]));
         }
+        uint4 *dst = chroma ? (uint4 *)&P_c[l][0][comp * (NPC * CS) + p * CS + 8 * o] : (uint4 *)&P_y[l][p * TS + 8 * o];
+        dst[0] = make_uint4(pack16(h[0][0], h[1][0]), pack16(h[0][1], h[1][1]), pack16(h[0][2], h[1][2]), pack16(h[0][3], h[1][3]));
+        dst[1] = make_uint4(pack16(h[0][4], h[1][4]), pack16(h[0][5], h[1][5]), pack16(h[0][6], h[1][6]), pack16(h[0][7], h[1][7]));
       }
     }
   }
@@ -627,8 +669,11 @@ __global__ __launch_bounds__(NTHR, 8) void k_inter_tile(const PicJob *jobs, SeqI
 
   // ---- phase V: one lane per two rows x four columns, result stored as one dword per row ----
   const bool bi = nl == 2;
-  // 8-bit samples: uni (v + 8192 + 32) >> 6, bi (v0 + v1 + 16384 + 64) >> 7
-  const int fsh = bi ? 7 : 6, foff = bi ? 16384 + 64 : 8192 + 32;
+  // uni: clip((v + 8192 + rnd) >> (14 - bd)); bi: TComYuv::addAvg, (v0 + v1 + 16384 + (1 << (14 - bd))) >> (15 - bd)
+  const int head_y = 14 - s.bd_y, head_c = 14 - s.bd_c;
+  const int fsh_y = bi ? head_y + 1 : head_y, foff_y = bi ? 16384 + (1 << head_y) : 8192 + (head_y ? 1 << (head_y - 1) : 0);
+  const int fsh_c = bi ? head_c + 1 : head_c, foff_c = bi ? 16384 + (1 << head_c) : 8192 + (head_c ? 1 << (head_c - 1) : 0);
+  const int max_y = (1 << s.bd_y) - 1, max_c = (1 << s.bd_c) - 1;
   constexpr int LT = TS * TS / 8, CT = 2 * CS * CS / 8;  // luma and chroma work items
   for (int v0 = 0; v0 < LT + CT; v0 += NTHR) {
     const int v = v0 + tid;
@@ -670,10 +715,16 @@ __global__ __launch_bounds__(NTHR, 8) void k_inter_tile(const PicJob *jobs, SeqI
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const int y = ry + 2 * rp + j;
-          if (y < s.h)
-            *(unsigned *)((uint8_t *)J.rec[0] + (size_t)y * s.stride_y + rx + 4 * q) =
-                pack4(tile_px(acc[j][0], foff, fsh), tile_px(acc[j][1], foff, fsh), tile_px(acc[j][2], foff, fsh),
-                      tile_px(acc[j][3], foff, fsh));
+          if (y < s.h) {
+            int px[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) px[c] = tile_px(acc[j][c], foff_y, fsh_y, max_y);
+            pel_t *o = (pel_t *)J.rec[0] + (size_t)y * s.stride_y + rx + 4 * q;
+            if constexpr (W16)
+              *(uint2 *)o = make_uint2(pack16(px[0], px[1]), pack16(px[2], px[3]));
+            else
+              *(unsigned *)o = pack4(px[0], px[1], px[2], px[3]);
+          }
         }
       }
     } else {
@@ -714,10 +765,16 @@ __global__ __launch_bounds__(NTHR, 8) void k_inter_tile(const PicJob *jobs, SeqI
 #pragma unroll
         for (int j = 0; j < 2; j++) {
           const int y = (ry >> 1) + 2 * rp + j;
-          if (y < s.ch)
-            *(unsigned *)((uint8_t *)J.rec[1 + comp] + (size_t)y * s.stride_c + cx) =
-                pack4(tile_px(acc[j][0], foff, fsh), tile_px(acc[j][1], foff, fsh), tile_px(acc[j][2], foff, fsh),
-                      tile_px(acc[j][3], foff, fsh));
+          if (y < s.ch) {
+            int px[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) px[c] = tile_px(acc[j][c], foff_c, fsh_c, max_c);
+            pel_t *o = (pel_t *)J.rec[1 + comp] + (size_t)y * s.stride_c + cx;
+            if constexpr (W16)
+              *(uint2 *)o = make_uint2(pack16(px[0], px[1]), pack16(px[2], px[3]));
+            else
+              *(unsigned *)o = pack4(px[0], px[1], px[2], px[3]);
+          }
         }
       }
     }
@@ -1497,11 +1554,11 @@ static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, 
     case K_INTER:
       // arg = 0..2: uniform regions of 64 / 32 / 16 samples, 3: mixed regions; arg2 = their largest count over the
       // batch.  Tile grid.x is a multiple of 8, so that blockIdx.x & 7 is the XCD for every picture of the batch.
-      if constexpr (sizeof(pel_t) == 1) {
+      {
         const dim3 g((arg2 + 7) / 8 * 8, n);
-        if (arg == 0) LAUNCH((k_inter_tile<64, 512>), g, dim3(512), st, jobs, s);
-        if (arg == 1) LAUNCH((k_inter_tile<32, 128>), g, dim3(128), st, jobs, s);
-        if (arg == 2) LAUNCH((k_inter_tile<16, 64>), g, dim3(64), st, jobs, s);
+        if (arg == 0) LAUNCH((k_inter_tile<pel_t, 64, 512>), g, dim3(512), st, jobs, s);
+        if (arg == 1) LAUNCH((k_inter_tile<pel_t, 32, 128>), g, dim3(128), st, jobs, s);
+        if (arg == 2) LAUNCH((k_inter_tile<pel_t, 16, 64>), g, dim3(64), st, jobs, s);
       }
       if (arg == 3) LAUNCH(k_inter_blk<pel_t>, dim3((arg2 + 15) / 16, n), dim3(256), st, jobs, s);
       break;

@@ -393,11 +393,10 @@ int PackedPicture::classify_mc(int x0, int y0, int size, McTile *out) const {
 void PackedPicture::split_mc(int x0, int y0, int level) {
   if (x0 >= seq.w || y0 >= seq.h) return;
   const int size = 64 >> level;
-  const bool tiles_ok = seq.bd_y <= 8 && seq.bd_c <= 8;  // the tile kernels work on byte planes
   McTile t;
   const int kind = classify_mc(x0, y0, size, &t);
   if (kind == MC_NONE) return;
-  if (kind == MC_UNIFORM && tiles_ok) {
+  if (kind == MC_UNIFORM) {
     mc_tile[level].push_back(t);
     return;
   }
