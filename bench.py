@@ -22,7 +22,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from hevc_amd import engine, syntax  # noqa: E402
+from hevc_amd import engine, sharding, syntax  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
 ID_STRIDE = 128         # picture ids of stream s are offset by s * ID_STRIDE
@@ -108,12 +108,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    backend = os.environ.get("HEVCRECON_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 path on fewer GPUs
     if world > 1:
         import torch
         import torch.distributed as dist
 
+        ndev = torch.cuda.device_count()
+        if backend == "nccl" and local_rank >= ndev:
+            raise SystemExit("bench: rank %d has no GPU of its own (%d visible)" % (local_rank, ndev))
+        local_rank = local_rank % max(ndev, 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     seq = syntax.read_dump(os.path.join(ROOT, "tests", "golden", args.fixture + ".syn.xz"))
     sp = seq.seq_params
@@ -165,12 +170,7 @@ def main():
         one_step()
     sync()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = sharding.max_over_ranks(elapsed, dist, device="cuda" if backend == "nccl" else "cpu")
 
     # ---- parity: one more (untimed) pass, every final picture of the first and last stream against the
     # reference decoder's MD5 right after its batch (the decoder recycles picture ids, so the check cannot wait)

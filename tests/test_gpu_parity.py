@@ -119,3 +119,40 @@ def test_drop_in_behind_reference_decoder_cli(bits, npics):
     out = r.stdout.decode("latin1")
     assert r.returncode == 0, out[-2000:]
     assert out.count("(OK)") == npics and "ERROR" not in out
+
+
+BENCH_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"}
+
+
+def _bench_line(cmd, env=None):
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable] + cmd, cwd=root, env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = out.stdout.decode("latin1")
+    assert out.returncode == 0, text[-2000:]
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, text[-2000:]  # exactly one JSON line (rank 0)
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_contract_single_gpu():
+    d = _bench_line(["bench.py", "--steps", "1", "--warmup", "1", "--streams", "2", "--no-cpu-baseline"])
+    assert BENCH_KEYS <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and d["config"]["md5_exact"]
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_over_gloo():
+    """The N > 1 path of the benchmark (rendezvous, barrier, max-over-ranks time, one line from rank 0), rehearsed
+    with two ranks on the one GPU of the test machine; the real multi-GPU run uses RCCL and one GPU per rank."""
+    d = _bench_line(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                     "29533", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--streams", "2", "--no-cpu-baseline"],
+                    env={"HEVCRECON_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
