@@ -1479,11 +1479,13 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
         for (int i = 0; i < 4; i++) o[1 + 4 * k + i] = (int)((w[k] >> (8 * i)) & 255);
       o[17] = (int)(r & 255);
     } else {
+      // 16 samples as two 16-byte vectors plus the two neighbours (rows are padded, see above)
+      const uint4 m0 = *(const uint4 *)(rp + x), m1 = *(const uint4 *)(rp + x + 8);
+      const unsigned w[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+      o[0] = x > 0 ? (int)rp[x - 1] : 0;
 #pragma unroll
-      for (int i = 0; i < 18; i++) {
-        const int xx = x + i - 1;
-        o[i] = (xx >= 0 && xx < pw) ? (int)rp[xx] : 0;
-      }
+      for (int i = 0; i < 16; i++) o[1 + i] = (int)((w[i >> 1] >> (16 * (i & 1))) & 0xffff);
+      o[17] = (int)rp[x + 16];
     }
   };
   int cur[18], v[16];
