@@ -8,8 +8,8 @@
 //   * int16   coeff[...]         coded coefficients, raster inside a block, blocks back to back
 //   * IntraItem intra[...]       one entry per intra prediction block, grouped by CTU, inside a CTU by local
 //                                dependency level; IntraCtu ictu[...] one entry per CTU that holds intra blocks,
-//                                sorted by CTU wave (a CTU's wave is one more than the highest wave among its left,
-//                                above-left, above and above-right neighbours that hold intra blocks)
+//                                sorted by CTU wave (a CTU's wave is one more than the highest wave among the
+//                                neighbouring CTUs whose intra blocks its own blocks read)
 //   * McTile  mc_tile[3][...] / McBlk mc_blk[...]  regions with uniform / mixed motion
 //   * SaoCtu  sao[nCtu*3]        SAO parameters per CTU and component
 // Sample planes are uint8 for 8-bit sequences and uint16 otherwise, with no margin: kernels clamp

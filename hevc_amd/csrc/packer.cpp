@@ -80,6 +80,7 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
   }
   ctu_items.clear();
   ctu_item_lvl.clear();
+  ctu_dep_wave = 0;
   const int cx = addr % seq.ctus_w, cy = addr / seq.ctus_w;
   walk_cu(ctu, cx * 64, cy * 64, 0, 0);
   if (!ctu_items.empty()) {
@@ -99,13 +100,9 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
     for (int l = 1; l <= nlev + 1; l++) start[l] += start[l - 1];
     intra.resize(ic.item_start + ctu_items.size());
     for (size_t i = 0; i < ctu_items.size(); i++) intra[ic.item_start + start[ctu_item_lvl[i]]++] = ctu_items[i];
-    // wave: after every neighbouring CTU whose intra blocks this CTU may read
-    int wave = 0;
-    const int nb[4][2] = {{-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
-    for (int k = 0; k < 4; k++) {
-      const int nx = cx + nb[k][0], ny = cy + nb[k][1];
-      if (nx >= 0 && ny >= 0 && nx < seq.ctus_w) wave = std::max<int>(wave, ctu_wave[(size_t)ny * seq.ctus_w + nx]);
-    }
+    // wave: after every neighbouring CTU whose intra blocks this CTU's blocks actually read (found while the
+    // blocks' neighbour masks were built)
+    const int wave = ctu_dep_wave;
     ctu_wave[addr] = (uint16_t)(wave + 1);
     ictu.push_back(ic);
     ictu_wave.push_back((uint16_t)(wave + 1));
@@ -224,8 +221,13 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
   // Local dependency level: one more than the highest level among the intra blocks OF THE SAME CTU that cover
   // an available neighbouring unit (blocks of other CTUs are finished before this CTU starts: CTU waves).
   const int my_cx = ux0 >> 4, my_cy = uy0 >> 4;
+  // A unit of ANOTHER CTU matters only when an intra block covers it: then this CTU has to wait for that CTU's
+  // wave (inter samples are final before any intra kernel runs).
   auto level_at = [&](int ux, int uy) -> int {
-    return ((ux >> 4) == my_cx && (uy >> 4) == my_cy) ? lvl[(size_t)uy * seq.uw + ux] : 0;
+    if ((ux >> 4) == my_cx && (uy >> 4) == my_cy) return lvl[(size_t)uy * seq.uw + ux];
+    if (rec4[(size_t)uy * seq.uw + ux].flags & P4_INTRA)
+      ctu_dep_wave = std::max<int>(ctu_dep_wave, ctu_wave[(size_t)(uy >> 4) * seq.ctus_w + (ux >> 4)]);
+    return 0;
   };
   int level = 0;
   uint16_t left = 0, above = 0;

@@ -35,6 +35,7 @@ struct PackedPicture {
   std::vector<uint16_t> lvl_y, lvl_c; // per 4x4 unit: local level of the intra block covering it (0 = none)
   std::vector<uint16_t> ctu_wave;     // per CTU: wave (0 = no intra blocks)
   std::vector<uint16_t> ictu_wave;    // parallel to ictu before sorting
+  int ctu_dep_wave;                   // highest wave among the CTUs whose intra blocks the CTU being added reads
 
   void begin(const SeqInfo &s);
   bool add_ctu(int addr, const hevcrecon_ctu_syntax *ctu);
