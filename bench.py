@@ -147,11 +147,16 @@ def main():
     prepared = [[engs[c].prepare_batch([syns[t][s] for s in groups[c]], [ids[t][s] for s in groups[c]]) for c in range(C)]
                 for t in range(npic)]
 
+    # Contexts run on their own HIP streams, so their kernels overlap on the GPU.  Independent streams are not in
+    # lock step in practice: context c works `phase[c]` pictures ahead (cyclically; the pictures a position refers
+    # to are resident from the previous pass), which lets one context's latency-bound intra waves run beside
+    # another's throughput-bound kernels.
+    phase = [c * npic // C for c in range(C)]
+
     def one_step():
-        # contexts run on their own HIP streams: their kernels overlap on the GPU
         for t in range(npic):
             for c in range(C):
-                engs[c].reconstruct_prepared(prepared[t][c])
+                engs[c].reconstruct_prepared(prepared[(t + phase[c]) % npic][c])
 
     def sync():
         for e in engs:
@@ -162,6 +167,10 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    if C > 1:  # one pass in decoding order makes every picture resident before the phase-shifted passes start
+        for t in range(npic):
+            for c in range(C):
+                engs[c].reconstruct_prepared(prepared[t][c])
     for _ in range(args.warmup):
         one_step()
     sync()
