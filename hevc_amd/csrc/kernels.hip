@@ -476,7 +476,12 @@ __device__ __forceinline__ int tile_px(int v, int off, int sh, int maxv = 255) {
 #endif
   return clip3i(0, maxv, x);
 }
+#ifdef HEVCRECON_EMULATE
 __device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+#else
+// low halves of two registers in one instruction (v_perm_b32: bytes 0,1 of lo, then bytes 0,1 of hi)
+__device__ __forceinline__ unsigned pack16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
+#endif
 
 struct __attribute__((packed)) HrBytes16 {
   unsigned v[4];
