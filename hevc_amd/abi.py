@@ -70,6 +70,17 @@ class CtuSyntax(C.Structure):
     ]
 
 
+class ScalingLists(C.Structure):
+    _fields_ = [
+        ("m4", (C.c_uint8 * 16) * 6),
+        ("m8", (C.c_uint8 * 64) * 6),
+        ("m16", (C.c_uint8 * 64) * 6),
+        ("m32", (C.c_uint8 * 64) * 2),
+        ("dc16", C.c_uint8 * 6),
+        ("dc32", C.c_uint8 * 2),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/hevcrecon.h declares
 _P = C.c_void_p
 _I16P = C.c_void_p
@@ -83,6 +94,7 @@ EXPORTS = {
     "hevcrecon_syntax_stats": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "hevcrecon_syntax_destroy": (None, [_P]),
     "hevcrecon_syntax_begin": (C.c_int, [_P]),
+    "hevcrecon_syntax_set_scaling_lists": (C.c_int, [_P, C.c_void_p]),
     "hevcrecon_syntax_add_ctu": (C.c_int, [_P, C.c_int, C.POINTER(CtuSyntax)]),
     "hevcrecon_syntax_finish": (C.c_int, [_P, C.POINTER(PicParams)]),
     "hevcrecon_reconstruct": (C.c_int, [_P, _P, C.c_int]),

@@ -93,6 +93,16 @@ struct IntraCtu {
   uint16_t cx, cy;     /* CTU position in CTUs */
 };
 
+// De-quantisation matrices of a picture that uses scaling lists (same content as hevcrecon_scaling_lists).
+struct ScalingTables {
+  uint8_t m4[6][16];
+  uint8_t m8[6][64];
+  uint8_t m16[6][64];
+  uint8_t m32[2][64];
+  uint8_t dc16[6];
+  uint8_t dc32[2];
+};
+
 struct SaoCtu {
   int8_t type; /* -1 off, 0..3 edge classes, 4 band */
   int8_t band; /* band position */
@@ -131,6 +141,7 @@ struct PicJob {
   const int32_t *wave_off;    /* n_waves + 1 entries into ictu[] */
   int32_t n_waves;
   const SaoCtu *sao;
+  const ScalingTables *scaling; /* NULL: flat de-quantisation */
   int32_t slice_type; /* 0 B, 1 P, 2 I */
   int32_t deblock_disable, beta_off_div2, tc_off_div2;
   int32_t cb_off_pps, cr_off_pps; /* deblocking uses the PPS offsets only */

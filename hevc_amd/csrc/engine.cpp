@@ -75,7 +75,7 @@ struct hevcrecon_syntax {
   size_t dev_cap = 0;
   char *host = nullptr;  // pinned staging
   size_t host_cap = 0;
-  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_mct[3] = {0, 0, 0}, off_mcb = 0;
+  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_mct[3] = {0, 0, 0}, off_mcb = 0, off_scal = 0;
   bool uploaded = false;
   std::string err;
 };
@@ -361,6 +361,15 @@ extern "C" int hevcrecon_syntax_begin(hevcrecon_syntax *s) {
   return 0;
 }
 
+extern "C" int hevcrecon_syntax_set_scaling_lists(hevcrecon_syntax *s, const hevcrecon_scaling_lists *l) {
+  if (!s) return 1;
+  static_assert(sizeof(ScalingTables) == sizeof(hevcrecon_scaling_lists), "scaling list layouts differ");
+  if (s->pk.finished) return fail(s->ctx, "scaling lists must be set between hevcrecon_syntax_begin and hevcrecon_syntax_finish");
+  s->pk.use_scaling = l != nullptr;
+  if (l) std::memcpy(&s->pk.scaling, l, sizeof(ScalingTables));
+  return 0;
+}
+
 extern "C" int hevcrecon_syntax_add_ctu(hevcrecon_syntax *s, int ctu_addr, const hevcrecon_ctu_syntax *ctu) {
   if (!s || !ctu) return 1;
   if (!s->pk.add_ctu(ctu_addr, ctu)) {
@@ -396,6 +405,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   s->off_sao = place(k.sao.size() * sizeof(SaoCtu));
   for (int i = 0; i < 3; i++) s->off_mct[i] = place(k.mc_tile[i].size() * sizeof(McTile));
   s->off_mcb = place(k.mc_blk.size() * sizeof(McBlk));
+  s->off_scal = place(sizeof(ScalingTables));
   const size_t upload_bytes = off;
   const size_t total = off;
   if (s->dev_cap < total) {
@@ -425,6 +435,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   std::memcpy(s->host + s->off_sao, k.sao.data(), k.sao.size() * sizeof(SaoCtu));
   for (int i = 0; i < 3; i++) std::memcpy(s->host + s->off_mct[i], k.mc_tile[i].data(), k.mc_tile[i].size() * sizeof(McTile));
   std::memcpy(s->host + s->off_mcb, k.mc_blk.data(), k.mc_blk.size() * sizeof(McBlk));
+  std::memcpy(s->host + s->off_scal, &k.scaling, sizeof(ScalingTables));
   HIPCHK(c, hipMemcpyAsync(s->dev, s->host, upload_bytes, hipMemcpyHostToDevice, c->stream));
   s->uploaded = true;
   return 0;
@@ -578,6 +589,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     j.n_waves = k.wave_off.empty() ? 0 : (int)k.wave_off.size() - 1;
     if (j.n_waves > max_levels) max_levels = j.n_waves;
     j.sao = (const SaoCtu *)(y->dev + y->off_sao);
+    j.scaling = k.use_scaling ? (const ScalingTables *)(y->dev + y->off_scal) : nullptr;
     j.slice_type = k.pp.slice_type;
     j.deblock_disable = k.pp.deblocking_disable;
     j.beta_off_div2 = k.pp.beta_offset_div2;

@@ -839,9 +839,35 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
   int dq[N];
 #pragma unroll
   for (int k = 0; k < N; k++) dq[k] = live ? (int)coef[k * N + c] : 0;
+  // Scaling lists (TComTrQuant::xDeQuant, scaling-list branch, TLibCommon/TComTrQuant.cpp:1142-1173): the lane's
+  // column meets at most 8 different matrix entries (one per matrix row; a 16x16 / 32x32 entry spans 2 / 4 rows)
+  const ScalingTables *sl = J.scaling;
+  int mrow[8] = {16, 16, 16, 16, 16, 16, 16, 16};
+  int mdc = 16;
+  if (sl && live) {
+    const int type = ((it.flags & TU_TO_RESI) ? 0 : 3) + comp;  // intra blocks are the ones that keep their residual
+    const uint8_t *m = LOG2N == 2 ? sl->m4[type] : LOG2N == 3 ? sl->m8[type] : LOG2N == 4 ? sl->m16[type] : sl->m32[type ? 1 : 0];
+    constexpr int MW = N < 8 ? N : 8, RATIO = N / MW;
+#pragma unroll
+    for (int r = 0; r < MW; r++) mrow[r] = m[r * MW + c / RATIO];
+    mdc = LOG2N == 4 ? sl->dc16[type] : LOG2N == 5 ? sl->dc32[type ? 1 : 0] : mrow[0];
+  }
+  const int sl_shift = shift + 4 - per;  // > 0: round and shift right; <= 0: shift left
+  const int sl_lim = 1 << min(15, 12 + LOG2N + bd - per);
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    const int d = clip3i(-32768, 32767, (dq[k] * scale + add) >> shift);
+    int d;
+    if (!sl) {
+      d = clip3i(-32768, 32767, (dq[k] * scale + add) >> shift);
+    } else {
+      constexpr int RATIO = N / (N < 8 ? N : 8);
+      const int mk = (RATIO > 1 && k == 0 && c == 0) ? mdc : mrow[k / RATIO];
+      const int coef = iq * mk;
+      if (sl_shift > 0)
+        d = clip3i(-32768, 32767, (dq[k] * coef + (1 << (sl_shift - 1))) >> sl_shift);
+      else
+        d = clip3i(-32768, 32767, (clip3i(-sl_lim, sl_lim - 1, dq[k]) * coef) << (-sl_shift));
+    }
     if (tskip) tmp[t_local][k][c] = d;  // transform-skip blocks bypass both passes: keep the de-quantised block as it is
     const int dd = tskip ? 0 : d;
     if (!__any(dd != 0)) continue;  // wave-uniform

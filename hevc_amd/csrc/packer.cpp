@@ -53,6 +53,7 @@ void PackedPicture::begin(const SeqInfo &s) {
   sao.assign((size_t)s.ctus_w * s.ctus_h * 3, SaoCtu());
   lvl_y.assign((size_t)s.uw * s.uh, 0);
   lvl_c.assign((size_t)s.uw * s.uh, 0);
+  use_scaling = false;
   mc_ref_samples = 0;
   max_ref_idx[0] = max_ref_idx[1] = -1;
   inter_without_ref = false;

@@ -28,6 +28,8 @@ class Syntax:
         """begin + add_ctu for every CTU + finish (which queues the upload)."""
         lib = self.lib
         self.engine._check(lib.hevcrecon_syntax_begin(self.h), "hevcrecon_syntax_begin")
+        if getattr(pic, "scaling", None) is not None:
+            self.engine._check(lib.hevcrecon_syntax_set_scaling_lists(self.h, C.addressof(pic.scaling)), "hevcrecon_syntax_set_scaling_lists")
         ctus = pic.ctu_structs()
         for a in range(pic.nctu):
             self.engine._check(lib.hevcrecon_syntax_add_ctu(self.h, a, C.byref(ctus[a])), "hevcrecon_syntax_add_ctu")

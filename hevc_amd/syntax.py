@@ -21,6 +21,7 @@ from . import abi
 
 MAGIC = b"HVSYN1\0\0"
 PICT = 0x54434950
+SCAL = 0x4C414353  # optional record before a picture: the scaling lists it de-quantises with
 P = abi.PARTS_PER_CTU
 
 # (name, dtype, elements per partition, count) in file order
@@ -50,6 +51,7 @@ class PictureSyntax:
         self.nctu = 0
         self.a = {}          # name -> array
         self.sao = None      # (nctu, 3, 6) int32: type, subtype, offset[4]
+        self.scaling = None  # abi.ScalingLists when the picture uses scaling lists
         self.stage_md5 = None  # (3, 3) hex strings: [stage][component]
         self.planes = None   # optional [stage][component] 2-D uint16
         self._keep = None
@@ -130,10 +132,17 @@ def read_dump(path, max_pictures=None):
             if len(hdr) < 16:
                 break
             tag, nctu, pic_id, has_planes = struct.unpack("<4i", hdr)
+            scaling = None
+            if tag == SCAL:
+                # the 16 bytes just read are the record's tag + 12 bytes of padding
+                scaling = abi.ScalingLists.from_buffer_copy(f.read(C.sizeof(abi.ScalingLists)))
+                hdr = f.read(16)
+                tag, nctu, pic_id, has_planes = struct.unpack("<4i", hdr)
             if tag != PICT:
                 raise ValueError("%s: bad picture tag" % path)
             pic = PictureSyntax()
             pic.nctu, pic.pic_id = nctu, pic_id
+            pic.scaling = scaling
             raw = f.read(C.sizeof(abi.PicParams))
             C.memmove(C.addressof(pic.pic_params), raw, len(raw))
 
@@ -180,6 +189,10 @@ def strip_planes_and_compress(src, dst, preset=6):
             if len(hdr) < 16:
                 break
             tag, nctu, pic_id, has_planes = struct.unpack("<4i", hdr)
+            if tag == SCAL:  # optional scaling-list record: copied as it is
+                out.write(hdr)
+                out.write(f.read(C.sizeof(abi.ScalingLists)))
+                continue
             body = C.sizeof(abi.PicParams) + nctu * (len(_U8_FIELDS) * P + 2 * 4 * P + 2 * P + 2 * P + (16 + 4 + 4) * P * 2 + 18 * 4) + 144
             out.write(struct.pack("<4i", tag, nctu, pic_id, 0))
             out.write(f.read(body))

@@ -100,6 +100,20 @@ typedef struct hevcrecon_ctu_syntax {
   int32_t sao_offset[3][4];
 } hevcrecon_ctu_syntax;
 
+/* Scaling lists in effect for a picture: the TComScalingList that TDecTop::xDecodeSlice has resolved from
+ * SPS / PPS / default tables and hands to m_cTrQuant.setScalingListDec (TLibDecoder/TDecTop.cpp:548-561).
+ * Matrices are raster (TComScalingList::getScalingListAddress); listId = (intra ? 0 : 3) + component;
+ * a 16x16 (32x32) entry covers 2x2 (4x4) coefficients and the DC entry is replaced by dc16 / dc32
+ * (TComTrQuant::processScalingListDec, TLibCommon/TComTrQuant.cpp:2577-2590); 32x32 has the two luma lists only. */
+typedef struct hevcrecon_scaling_lists {
+  uint8_t m4[6][16];
+  uint8_t m8[6][64];
+  uint8_t m16[6][64];
+  uint8_t m32[2][64]; /* 0 intra luma, 1 inter luma */
+  uint8_t dc16[6];
+  uint8_t dc32[2];
+} hevcrecon_scaling_lists;
+
 /* ---- context ---------------------------------------------------------- */
 
 /* Creates an engine on HIP device `device`.  Fails (non-zero, *out = NULL) when no GPU is present. */
@@ -135,6 +149,12 @@ int hevcrecon_syntax_stats(const hevcrecon_syntax *syn, int64_t out[32]);
 /* Start a new picture in `syn` (drops whatever it held).  Stands where TDecTop::xDecodeSlice
  * obtains the picture buffer for a first slice (TLibDecoder/TDecTop.cpp:358-376). */
 int hevcrecon_syntax_begin(hevcrecon_syntax *syn);
+
+/* Optional, between hevcrecon_syntax_begin and hevcrecon_syntax_finish: the picture de-quantises with these
+ * scaling lists (TComTrQuant::xDeQuant, scaling-list branch, TLibCommon/TComTrQuant.cpp:1142-1173) instead of
+ * the flat path.  Replaces m_cTrQuant.setScalingListDec / setUseScalingList(true) (TLibDecoder/TDecTop.cpp:560-561).
+ * NULL returns to flat de-quantisation.  hevcrecon_syntax_begin resets to flat. */
+int hevcrecon_syntax_set_scaling_lists(hevcrecon_syntax *syn, const hevcrecon_scaling_lists *lists);
 
 /* Replaces the call m_pcCuDecoder->decompressCU(pcCU) in TDecSlice::decompressSlice
  * (TLibDecoder/TDecSlice.cpp:367): instead of reconstructing the CTU at once, its syntax

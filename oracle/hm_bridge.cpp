@@ -57,6 +57,7 @@ struct EngineApi {
   int (*sequence_init)(hevcrecon_ctx *, const hevcrecon_seq_params *);
   int (*syntax_create)(hevcrecon_ctx *, hevcrecon_syntax **);
   int (*syntax_begin)(hevcrecon_syntax *);
+  int (*syntax_set_scaling_lists)(hevcrecon_syntax *, const hevcrecon_scaling_lists *);
   int (*syntax_add_ctu)(hevcrecon_syntax *, int, const hevcrecon_ctu_syntax *);
   int (*syntax_finish)(hevcrecon_syntax *, const hevcrecon_pic_params *);
   int (*reconstruct)(hevcrecon_ctx *, hevcrecon_syntax *, int);
@@ -106,6 +107,7 @@ struct Bridge {
     sym(api.sequence_init, "hevcrecon_sequence_init");
     sym(api.syntax_create, "hevcrecon_syntax_create");
     sym(api.syntax_begin, "hevcrecon_syntax_begin");
+    sym(api.syntax_set_scaling_lists, "hevcrecon_syntax_set_scaling_lists");
     sym(api.syntax_add_ctu, "hevcrecon_syntax_add_ctu");
     sym(api.syntax_finish, "hevcrecon_syntax_finish");
     sym(api.reconstruct, "hevcrecon_reconstruct");
@@ -156,6 +158,25 @@ struct Bridge {
         pp.ref_poc[l][i] = sl->getRefPic(RefPicList(l), i)->getPOC();
       }
     }
+  }
+
+  // The scaling lists the decoder activated for this picture's slice (TLibDecoder/TDecTop.cpp:548-561).
+  bool fill_scaling(TComPic *pic, hevcrecon_scaling_lists &sl) {
+    TComSlice *s = pic->getSlice(pic->getCurrSliceIdx());
+    if (!s->getSPS()->getScalingListFlag()) return false;
+    TComScalingList *l = s->getScalingList();
+    memset(&sl, 0, sizeof(sl));
+    for (int id = 0; id < 6; id++) {
+      for (int i = 0; i < 16; i++) sl.m4[id][i] = (uint8_t)l->getScalingListAddress(SCALING_LIST_4x4, id)[i];
+      for (int i = 0; i < 64; i++) sl.m8[id][i] = (uint8_t)l->getScalingListAddress(SCALING_LIST_8x8, id)[i];
+      for (int i = 0; i < 64; i++) sl.m16[id][i] = (uint8_t)l->getScalingListAddress(SCALING_LIST_16x16, id)[i];
+      sl.dc16[id] = (uint8_t)l->getScalingListDC(SCALING_LIST_16x16, id);
+    }
+    for (int id = 0; id < 2; id++) {
+      for (int i = 0; i < 64; i++) sl.m32[id][i] = (uint8_t)l->getScalingListAddress(SCALING_LIST_32x32, id)[i];
+      sl.dc32[id] = (uint8_t)l->getScalingListDC(SCALING_LIST_32x32, id);
+    }
+    return true;
   }
 
   void fill_ctu(TComPic *pic, int addr, const hevcrecon_pic_params &pp, hevcrecon_ctu_syntax &cs, int8_t *refbuf) {
@@ -236,6 +257,12 @@ struct Bridge {
     hevcrecon_pic_params pp;
     fill_pic(pic, pp);
     int nctu = pic->getNumCUsInFrame();
+    hevcrecon_scaling_lists sl;
+    if (fill_scaling(pic, sl)) {  // optional record in front of the picture
+      int32_t shdr[4] = {0x4C414353 /* "SCAL" */, 0, 0, 0};
+      put(shdr, 4);
+      put(&sl, 1);
+    }
     int32_t hdr[4] = {0x54434950 /* "PICT" */, nctu, pic_id(pic), dump_planes ? 1 : 0};
     put(hdr, 4);
     put(&pp, 1);
@@ -291,6 +318,8 @@ struct Bridge {
     hevcrecon_pic_params pp;
     fill_pic(pic, pp);
     if (api.syntax_begin(syn)) fail("hevcrecon_syntax_begin");
+    hevcrecon_scaling_lists sl;
+    if (fill_scaling(pic, sl) && api.syntax_set_scaling_lists(syn, &sl)) fail("hevcrecon_syntax_set_scaling_lists");
     int nctu = pic->getNumCUsInFrame();
     for (int a = 0; a < nctu; a++) {
       hevcrecon_ctu_syntax cs;

@@ -36,6 +36,8 @@ typedef struct hevcref_ctx {
   /* per-call state */
   const hevcrecon_pic_params *pp;
   const hevcrecon_ctu_syntax *ctus;
+  int use_sl;                 /* de-quantise with the scaling lists below */
+  hevcrecon_scaling_lists sl;
   int16_t *rec[3];
   uint8_t zscan_x[NPART], zscan_y[NPART]; /* partition z index -> x,y in 4-sample units */
   uint8_t raster_to_z[16][16];             /* [y][x] -> z */
@@ -171,7 +173,7 @@ static int scaled_qp(const hevcref_ctx *c, int qpy, int comp) {
 /* xDeQuant (flat scaling), TLibCommon/TComTrQuant.cpp:1119-1186; then xIT / xITransformSkip /
  * bypass as selected by invtransformNxN, TLibCommon/TComTrQuant.cpp:1267-1290.
  * coef: n*n int32 raster.  out: n*n residual, raster with stride n. */
-static void inverse_tu(const hevcref_ctx *c, const int32_t *coef, int log2n, int comp, int qpy, int use_dst, int tskip,
+static void inverse_tu(const hevcref_ctx *c, const int32_t *coef, int log2n, int comp, int intra, int qpy, int use_dst, int tskip,
                        int bypass, int16_t *out) {
   int n = 1 << log2n, nn = n * n;
   if (bypass) {
@@ -185,9 +187,33 @@ static void inverse_tu(const hevcref_ctx *c, const int32_t *coef, int log2n, int
   int add = 1 << (shift - 1);
   int scale = kInvQuant[rem] << per;
   int16_t dq[32 * 32];
-  for (int i = 0; i < nn; i++) {
-    int v = clip3(-32768, 32767, coef[i]);
-    dq[i] = (int16_t)clip3(-32768, 32767, (v * scale + add) >> shift);
+  if (c->use_sl) {
+    /* scaling-list branch of xDeQuant, TLibCommon/TComTrQuant.cpp:1142-1173, with the de-quantisation
+     * coefficients of xSetScalingListDec / processScalingListDec (:2486-2590): invQuantScales[rem] * matrix entry,
+     * an entry of the 8x8 base matrix covering ratio x ratio coefficients, DC replaced for 16x16 and 32x32 */
+    int type = (intra ? 0 : 3) + comp;
+    int mw = n < 8 ? n : 8, ratio = n / mw;
+    const uint8_t *m = log2n == 2 ? c->sl.m4[type] : log2n == 3 ? c->sl.m8[type] : log2n == 4 ? c->sl.m16[type] : c->sl.m32[type ? 1 : 0];
+    int dc = log2n == 4 ? c->sl.dc16[type] : log2n == 5 ? c->sl.dc32[type ? 1 : 0] : m[0];
+    int sh = shift + 4;
+    int bit_range = imin(15, 12 + log2n + bd - per), limit = 1 << bit_range;
+    for (int j = 0; j < n; j++)
+      for (int i = 0; i < n; i++) {
+        int mk = (ratio > 1 && i == 0 && j == 0) ? dc : m[mw * (j / ratio) + i / ratio];
+        int dcoef = kInvQuant[rem] * mk;
+        int q0 = coef[j * n + i], r;
+        if (sh > per) {
+          r = (clip3(-32768, 32767, q0) * dcoef + (1 << (sh - per - 1))) >> (sh - per);
+        } else {
+          r = (clip3(-limit, limit - 1, q0) * dcoef) << (per - sh);
+        }
+        dq[j * n + i] = (int16_t)clip3(-32768, 32767, r);
+      }
+  } else {
+    for (int i = 0; i < nn; i++) {
+      int v = clip3(-32768, 32767, coef[i]);
+      dq[i] = (int16_t)clip3(-32768, 32767, (v * scale + add) >> shift);
+    }
   }
   if (tskip) { /* TLibCommon/TComTrQuant.cpp:1454-1486 */
     int s = 15 - bd - log2n;
@@ -352,7 +378,7 @@ static void inter_residual(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu
   int16_t blk[32 * 32];
   const int32_t *coef = ctu->coeff[comp] + (comp ? 4 * z : 16 * z);
   int bypass = ctu->transquant_bypass ? ctu->transquant_bypass[z] : 0;
-  inverse_tu(c, coef, tlog2, comp, ctu->qp[zcu], 0, ctu->transform_skip[comp][z], bypass, blk);
+  inverse_tu(c, coef, tlog2, comp, 0, ctu->qp[zcu], 0, ctu->transform_skip[comp][z], bypass, blk);
   int n = 1 << tlog2;
   for (int j = 0; j < n; j++)
     for (int i = 0; i < n; i++) resi[(ty + j) * rstride + tx + i] = blk[j * n + i];
@@ -565,7 +591,7 @@ static void intra_block(hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int zcu
   intra_predict(c, comp, n, mode, use, pred);
   const int32_t *coef = ctu->coeff[comp] + (comp ? 4 * z : 16 * z);
   int bypass = ctu->transquant_bypass ? ctu->transquant_bypass[z] : 0;
-  inverse_tu(c, coef, log2, comp, ctu->qp[zcu], comp == 0 && log2 == 2, ctu->transform_skip[comp][z], bypass, resi);
+  inverse_tu(c, coef, log2, comp, 1, ctu->qp[zcu], comp == 0 && log2 == 2, ctu->transform_skip[comp][z], bypass, resi);
   int pw = plane_w(c, comp), maxv = (1 << bit_depth(c, comp)) - 1;
   for (int y = 0; y < n; y++)
     for (int x = 0; x < n; x++) c->rec[comp][(y0 + y) * pw + x0 + x] = (int16_t)clip3(0, maxv, pred[y * n + x] + resi[y * n + x]);
@@ -865,6 +891,12 @@ static void sao_ctu(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int c
 
 /* ---------------------------------------------------------------- entry points ----- */
 
+/* Scaling lists for the pictures reconstructed from now on (NULL: flat de-quantisation). */
+void hevcref_set_scaling_lists(hevcref_ctx *c, const hevcrecon_scaling_lists *sl) {
+  c->use_sl = sl != NULL;
+  if (sl) c->sl = *sl;
+}
+
 int hevcref_reconstruct(hevcref_ctx *c, const hevcrecon_pic_params *pp, const hevcrecon_ctu_syntax *ctus, int nctu, int dst_id) {
   if (nctu != c->nctu) return 1;
   Pic *dst = get_pic(c, dst_id);
@@ -925,5 +957,5 @@ int hevcref_upload(hevcref_ctx *c, int pic_id, int poc, const int16_t *y, const 
 void hevcref_inverse_tu(hevcref_ctx *c, const hevcrecon_pic_params *pp, const int32_t *coef, int log2n, int comp, int qpy,
                         int use_dst, int tskip, int16_t *out) {
   c->pp = pp;
-  inverse_tu(c, coef, log2n, comp, qpy, use_dst, tskip, 0, out);
+  inverse_tu(c, coef, log2n, comp, use_dst, qpy, use_dst, tskip, 0, out);
 }

@@ -30,6 +30,7 @@ def _load():
     lib.hevcref_reconstruct.argtypes = [V, C.POINTER(abi.PicParams), C.POINTER(abi.CtuSyntax), C.c_int, C.c_int]
     lib.hevcref_download.argtypes = [V, C.c_int, C.c_int, V, V, V]
     lib.hevcref_upload.argtypes = [V, C.c_int, C.c_int, V, V, V]
+    lib.hevcref_set_scaling_lists.argtypes = [V, V]
     lib.hevcref_inverse_tu.argtypes = [V, C.POINTER(abi.PicParams), V, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, V]
     return lib
 
@@ -50,6 +51,8 @@ class RefModel:
             self.ctx = None
 
     def reconstruct(self, pic, dst_id=None):
+        sl = getattr(pic, "scaling", None)
+        self.lib.hevcref_set_scaling_lists(self.ctx, C.addressof(sl) if sl is not None else None)
         ctus = pic.ctu_structs()
         rc = self.lib.hevcref_reconstruct(self.ctx, C.byref(pic.pic_params), ctus, pic.nctu, pic.pic_id if dst_id is None else dst_id)
         if rc:

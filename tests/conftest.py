@@ -8,7 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-STREAMS_240 = ["lowdelay_P_main", "randomaccess_main", "randomaccess_he10", "intra_main"]
+# "scalinglist": encoder_randomaccess_main.cfg with --ScalingList=1 (default scaling lists)
+STREAMS_240 = ["lowdelay_P_main", "randomaccess_main", "randomaccess_he10", "intra_main", "scalinglist"]
 
 
 def pytest_configure(config):

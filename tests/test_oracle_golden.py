@@ -79,3 +79,18 @@ def test_oracle_matches_reference_1080p(stream, npics):
                 assert syntax.plane_md5(planes[c], bd[c]) == pic.stage_md5[stage][c], (stream, poc, stage, c)
         pic.drop_ctypes()
     ref.close()
+
+
+def test_scaling_lists_are_what_makes_the_scalinglist_stream_match():
+    """Negative control for the scaling-list fixture: de-quantised flat, its first picture must NOT reproduce the
+    reference's digest (so the stream really exercises the scaling-list branch of the de-quantiser)."""
+    import copy
+
+    seq = load_golden("scalinglist_416x240", 1)
+    pic = copy.copy(seq.pictures[0])
+    assert pic.scaling is not None
+    pic.scaling = None
+    ref = RefModel(seq.seq_params)
+    ref.reconstruct(pic)
+    luma = ref.download(2, pic.pic_id)[0]
+    assert syntax.plane_md5(luma, seq.seq_params.bit_depth_luma) != pic.stage_md5[2][0]
