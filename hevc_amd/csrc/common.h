@@ -47,7 +47,7 @@ struct __attribute__((aligned(16))) Part4 {
 #define TU_TSKIP 0x01
 #define TU_DST 0x02
 #define TU_TO_RESI 0x04 /* intra block: write the residual to the residual planes, else add it to the picture */
-#define TU_BYPASS 0x08
+#define TU_BYPASS 0x08 /* lossless coding unit: the coefficients ARE the residual */
 
 struct TuItem {
   uint16_t x, y;     /* block position in its component plane */
@@ -147,6 +147,7 @@ struct PicJob {
   int32_t cb_off_pps, cr_off_pps; /* deblocking uses the PPS offsets only */
   int32_t cb_off, cr_off;         /* PPS offset + slice delta, for de-quantisation */
   int32_t sao_luma, sao_chroma;
+  int32_t has_bypass; /* some coding unit is lossless: SAO has to leave its samples alone */
   int32_t *error_flag;
 };
 

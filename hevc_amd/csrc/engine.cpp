@@ -600,6 +600,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     j.cr_off = k.pp.cr_qp_offset_pps + k.pp.cr_qp_delta_slice;
     j.sao_luma = k.pp.sao_luma;
     j.sao_chroma = k.pp.sao_chroma;
+    j.has_bypass = k.has_bypass ? 1 : 0;
     j.error_flag = c->error_flag_dev;
     any_deblock = any_deblock || !k.pp.deblocking_disable;
   }

@@ -829,6 +829,8 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
   const int shift = bd + LOG2N - 9, add = 1 << (shift - 1);
   const int16_t *coef = J.coeff + it.coeff_off;
   const bool tskip = (it.flags & TU_TSKIP) != 0;
+  // lossless coding unit (TComTrQuant::invtransformNxN, TLibCommon/TComTrQuant.cpp:1269-1279): residual = coefficients
+  const bool bypass = (it.flags & TU_BYPASS) != 0;
   const bool dst4 = LOG2N == 2 && (it.flags & TU_DST);
 
   // ---- pass 1 (columns) ----
@@ -869,7 +871,8 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
         d = clip3i(-32768, 32767, (clip3i(-sl_lim, sl_lim - 1, dq[k]) * coef) << (-sl_shift));
     }
     if (tskip) tmp[t_local][k][c] = d;  // transform-skip blocks bypass both passes: keep the de-quantised block as it is
-    const int dd = tskip ? 0 : d;
+    if (bypass) tmp[t_local][k][c] = dq[k];
+    const int dd = (tskip || bypass) ? 0 : d;
     if (!__any(dd != 0)) continue;  // wave-uniform
 #pragma unroll
     for (int y = 0; y < N; y++) {
@@ -878,7 +881,7 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
       acc[y] += __mul24(dst4 ? md : m, dd);  // 8-bit x 16-bit: the 24-bit multiplier is exact and runs at full rate
     }
   }
-  if (!tskip) {
+  if (!tskip && !bypass) {
 #pragma unroll
     for (int y = 0; y < N; y++) tmp[t_local][y][c] = clip3i(-32768, 32767, (acc[y] + 64) >> 7);
   }
@@ -893,7 +896,7 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
   for (int k = 0; k < N; k++) row[k] = tmp[t_local][y][k];
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    const int v = tskip ? 0 : row[k];
+    const int v = (tskip || bypass) ? 0 : row[k];
     if (!__any(v != 0)) continue;  // wave-uniform
 #pragma unroll
     for (int x = 0; x < N; x++) {
@@ -902,7 +905,10 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
       res[x] += __mul24(dst4 ? md : m, v);
     }
   }
-  if (tskip) {
+  if (bypass) {
+#pragma unroll
+    for (int x = 0; x < N; x++) res[x] = row[x];
+  } else if (tskip) {
     const int ts = 15 - bd - LOG2N;  // > 0 for every supported bit depth
 #pragma unroll
     for (int x = 0; x < N; x++) res[x] = (row[x] + (1 << (ts - 1))) >> ts;
@@ -1401,6 +1407,9 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
   }
   const int bs = boundary_strength(J, P, Q, tu_edge);
   if (!bs) return;
+  // a side that belongs to a lossless coding unit is left as it is (bPartPNoFilter / bPartQNoFilter,
+  // TLibCommon/TComLoopFilter.cpp:633-642,856-867; TComDataCU::isLosslessCoded, TLibCommon/TComDataCU.cpp:1703-1706)
+  const bool keep_p = (P.flags & P4_BYPASS) != 0, keep_q = (Q.flags & P4_BYPASS) != 0;
   const int qp = (P.qp + Q.qp + 1) >> 1;
   {
     const int scale = 1 << (s.bd_y - 8), maxv = (1 << s.bd_y) - 1;
@@ -1429,21 +1438,29 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
         const int m0 = m[k][0], m1 = m[k][1], m2 = m[k][2], m3 = m[k][3], m4 = m[k][4], m5 = m[k][5], m6 = m[k][6], m7 = m[k][7];
         pel_t *o = sp + k * line;
         if (sw) {
-          o[-step] = (pel_t)clip3i(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
-          o[0] = (pel_t)clip3i(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
-          o[-2 * step] = (pel_t)clip3i(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
-          o[step] = (pel_t)clip3i(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
-          o[-3 * step] = (pel_t)clip3i(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
-          o[2 * step] = (pel_t)clip3i(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
+          if (!keep_p) {
+            o[-step] = (pel_t)clip3i(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
+            o[-2 * step] = (pel_t)clip3i(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
+            o[-3 * step] = (pel_t)clip3i(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
+          }
+          if (!keep_q) {
+            o[0] = (pel_t)clip3i(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
+            o[step] = (pel_t)clip3i(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
+            o[2 * step] = (pel_t)clip3i(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
+          }
         } else {
           int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
           if (iabs(delta) < tc * 10) {
             delta = clip3i(-tc, tc, delta);
-            o[-step] = (pel_t)clip3i(0, maxv, m3 + delta);
-            o[0] = (pel_t)clip3i(0, maxv, m4 - delta);
             const int tc2 = tc >> 1;
-            if (fp) o[-2 * step] = (pel_t)clip3i(0, maxv, m2 + clip3i(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)));
-            if (fq) o[step] = (pel_t)clip3i(0, maxv, m5 + clip3i(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
+            if (!keep_p) {
+              o[-step] = (pel_t)clip3i(0, maxv, m3 + delta);
+              if (fp) o[-2 * step] = (pel_t)clip3i(0, maxv, m2 + clip3i(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)));
+            }
+            if (!keep_q) {
+              o[0] = (pel_t)clip3i(0, maxv, m4 - delta);
+              if (fq) o[step] = (pel_t)clip3i(0, maxv, m5 + clip3i(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
+            }
           }
         }
       }
@@ -1464,8 +1481,8 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
         pel_t *o = sp + k * line;
         const int m2 = o[-2 * step], m3 = o[-step], m4 = o[0], m5 = o[step];
         const int delta = clip3i(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
-        o[-step] = (pel_t)clip3i(0, maxv, m3 + delta);
-        o[0] = (pel_t)clip3i(0, maxv, m4 - delta);
+        if (!keep_p) o[-step] = (pel_t)clip3i(0, maxv, m3 + delta);
+        if (!keep_q) o[0] = (pel_t)clip3i(0, maxv, m4 - delta);
       }
     }
   }
@@ -1553,6 +1570,17 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
         c = clip3i(0, maxv, c + (o << inc));
       }
       v[i] = c;
+    }
+  }
+  if (J.has_bypass) {
+    // TComSampleAdaptiveOffset::xPCMRestoration (TLibCommon/TComSampleAdaptiveOffset.cpp:1394-1515): after SAO the
+    // samples of lossless coding units are put back to their reconstruction, which deblocking has not touched either
+    const int ush = comp ? 1 : 2;  // log2 of the plane's samples per 4x4 luma unit
+    const int uy = y >> ush;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const int ux = (x + i) >> ush;
+      if (ux < s.uw && (J.rec4[(size_t)uy * s.uw + ux].flags & P4_BYPASS)) v[i] = cur[i + 1];
     }
   }
   pel_t *orow = dst + (size_t)y * stride + x;

@@ -54,6 +54,7 @@ void PackedPicture::begin(const SeqInfo &s) {
   lvl_y.assign((size_t)s.uw * s.uh, 0);
   lvl_c.assign((size_t)s.uw * s.uh, 0);
   use_scaling = false;
+  has_bypass = false;
   mc_ref_samples = 0;
   max_ref_idx[0] = max_ref_idx[1] = -1;
   inter_without_ref = false;
@@ -150,10 +151,11 @@ void PackedPicture::walk_cu(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy,
       for (int l = 0; l < 2; l++) max_ref_idx[l] = std::max<int>(max_ref_idx[l], p.ref_idx[l]);
     }
   }
-  if ((ctu->ipcm && ctu->ipcm[z]) || (ctu->transquant_bypass && ctu->transquant_bypass[z])) {
-    error = "IPCM / transquant-bypass coding units are not supported";
+  if (ctu->ipcm && ctu->ipcm[z]) {
+    error = "IPCM coding units are not supported";
     return;
   }
+  if (ctu->transquant_bypass && ctu->transquant_bypass[z]) has_bypass = true;
   if (intra) {
     // TDecCu::xReconIntraQT, TLibDecoder/TDecCu.cpp:652-674: all luma blocks of the CU, then all chroma blocks.
     const int parts = ctu->part_size[z] == 3 ? 4 : 1;
@@ -180,7 +182,8 @@ void PackedPicture::emit_tu(const hevcrecon_ctu_syntax *ctu, int comp, int z, in
   t.x = (uint16_t)x;
   t.y = (uint16_t)y;
   t.comp = (uint8_t)comp;
-  t.flags = (uint8_t)(flags | (ctu->transform_skip[comp][z] ? TU_TSKIP : 0));
+  t.flags = (uint8_t)(flags | (ctu->transform_skip[comp][z] ? TU_TSKIP : 0) |
+                      ((ctu->transquant_bypass && ctu->transquant_bypass[z]) ? TU_BYPASS : 0));
   t.qp = ctu->qp[zcu];
   t.coeff_off = (uint32_t)off;
   tu[log2n - 2].push_back(t);

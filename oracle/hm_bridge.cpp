@@ -2,13 +2,14 @@
 //
 // TEST INFRASTRUCTURE.  This file is compiled together with the reference's own
 // sources (from where they lie, never copied) into oracle/_ref/TAppDecoderBridge.
-// It takes over four reference call sites WITHOUT editing reference source: the build
+// It takes over five reference call sites WITHOUT editing reference source: the build
 // renames the reference's definitions with -D macros (see oracle/Makefile) and this
 // file supplies the symbols the rest of the decoder links against:
 //
 //   TDecCu::decompressCU            TLibDecoder/TDecSlice.cpp:367   (per-CTU reconstruction)
 //   TComLoopFilter::loopFilterPic   TLibDecoder/TDecGop.cpp:181     (deblocking)
 //   TComSampleAdaptiveOffset::SAOProcess  TLibDecoder/TDecGop.cpp:199 (SAO)
+//   TComSampleAdaptiveOffset::PCMLFDisableProcess  TLibDecoder/TDecGop.cpp:200 (restoring lossless units after SAO)
 //   TComPic::compressMotion         TLibDecoder/TDecGop.cpp:210     (observation point only)
 //
 // Modes (environment variable HEVCRECON_MODE):
@@ -33,6 +34,7 @@
 #define decompressCU decompressCU_ref(TComDataCU *pcCU); Void decompressCU
 #define loopFilterPic loopFilterPic_ref(TComPic *pcPic); Void loopFilterPic
 #define SAOProcess SAOProcess_ref(SAOParam *pcSaoParam); Void SAOProcess
+#define PCMLFDisableProcess PCMLFDisableProcess_ref(TComPic *pcPic); Void PCMLFDisableProcess
 #define compressMotion compressMotion_ref(); Void compressMotion
 #include "TLibDecoder/TDecCu.h"
 #include "TLibCommon/TComLoopFilter.h"
@@ -41,6 +43,7 @@
 #undef decompressCU
 #undef loopFilterPic
 #undef SAOProcess
+#undef PCMLFDisableProcess
 #undef compressMotion
 #include "libmd5/MD5.h"
 
@@ -363,6 +366,13 @@ Void TComLoopFilter::loopFilterPic(TComPic *pcPic) {
 Void TComSampleAdaptiveOffset::SAOProcess(SAOParam *pcSaoParam) {
   if (bridge().mode == MODE_ENGINE) return;  // already applied by the engine
   SAOProcess_ref(pcSaoParam);
+}
+
+Void TComSampleAdaptiveOffset::PCMLFDisableProcess(TComPic *pcPic) {
+  // the engine has already put lossless coding units back; the reference would copy from per-CU buffers that
+  // its skipped reconstruction never filled
+  if (bridge().mode == MODE_ENGINE) return;
+  PCMLFDisableProcess_ref(pcPic);
 }
 
 Void TComPic::compressMotion() {

@@ -741,8 +741,9 @@ static int chroma_qp_deblock(int q) { return q < 0 ? q : (q > 57 ? q - 6 : kChro
 
 /* TComLoopFilter::xEdgeFilterLuma + xPelFilterLuma, TLibCommon/TComLoopFilter.cpp:546-660,809-868:
  * one 4-sample segment.  s points at q0 of the first line; step = distance across the edge,
- * line = distance between the 4 lines. */
-static void filter_luma_segment(const hevcref_ctx *c, int16_t *s, int step, int line, int bs, int qp) {
+ * line = distance between the 4 lines.  keep_p / keep_q: that side belongs to a lossless coding unit and is
+ * put back after filtering (bPartPNoFilter / bPartQNoFilter, :633-642,856-867). */
+static void filter_luma_segment(const hevcref_ctx *c, int16_t *s, int step, int line, int bs, int qp, int keep_p, int keep_q) {
   const hevcrecon_pic_params *pp = c->pp;
   int scale = 1 << (c->sp.bit_depth_luma - 8), maxv = (1 << c->sp.bit_depth_luma) - 1;
   int tc = kTc[clip3(0, 53, qp + 2 * (bs - 1) + 2 * pp->tc_offset_div2)] * scale;
@@ -781,6 +782,8 @@ static void filter_luma_segment(const hevcref_ctx *c, int16_t *s, int step, int 
         if (fq) Q(1, k) = (int16_t)clip3(0, maxv, m5 + clip3(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
       }
     }
+    if (keep_p) P(0, k) = (int16_t)m3, P(1, k) = (int16_t)m2, P(2, k) = (int16_t)m1;
+    if (keep_q) Q(0, k) = (int16_t)m4, Q(1, k) = (int16_t)m5, Q(2, k) = (int16_t)m6;
   }
 #undef P
 #undef Q
@@ -788,7 +791,7 @@ static void filter_luma_segment(const hevcref_ctx *c, int16_t *s, int step, int 
 
 /* TComLoopFilter::xEdgeFilterChroma + xPelFilterChroma, TLibCommon/TComLoopFilter.cpp:663-792,879-900:
  * the two chroma lines belonging to one 4-luma-sample unit. */
-static void filter_chroma_segment(const hevcref_ctx *c, int16_t *s, int step, int line, int qp_avg, int pps_off) {
+static void filter_chroma_segment(const hevcref_ctx *c, int16_t *s, int step, int line, int qp_avg, int pps_off, int keep_p, int keep_q) {
   int scale = 1 << (c->sp.bit_depth_chroma - 8), maxv = (1 << c->sp.bit_depth_chroma) - 1;
   int qp = chroma_qp_deblock(qp_avg + pps_off);
   int tc = kTc[clip3(0, 53, qp + 2 + 2 * c->pp->tc_offset_div2)] * scale;
@@ -796,8 +799,8 @@ static void filter_chroma_segment(const hevcref_ctx *c, int16_t *s, int step, in
     int16_t *m = s + k * line;
     int m2 = m[-2 * step], m3 = m[-step], m4 = m[0], m5 = m[step];
     int delta = clip3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
-    m[-step] = (int16_t)clip3(0, maxv, m3 + delta);
-    m[0] = (int16_t)clip3(0, maxv, m4 - delta);
+    if (!keep_p) m[-step] = (int16_t)clip3(0, maxv, m3 + delta);
+    if (!keep_q) m[0] = (int16_t)clip3(0, maxv, m4 - delta);
   }
 }
 
@@ -842,11 +845,14 @@ static void deblock_cu(hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int ctux
       PartRef p = dir == 0 ? part_at(c, x - 1, y) : part_at(c, x, y - 1);
       int qp_avg = (p.ctu->qp[p.z] + q.ctu->qp[q.z] + 1) >> 1;
       int16_t *s = c->rec[0] + y * c->w + x;
-      filter_luma_segment(c, s, dir == 0 ? 1 : c->w, dir == 0 ? c->w : 1, bs, qp_avg);
+      /* TComDataCU::isLosslessCoded, TLibCommon/TComDataCU.cpp:1703-1706 (the CU flag is only ever set when the PPS enables it) */
+      int keep_p = p.ctu->transquant_bypass && p.ctu->transquant_bypass[p.z];
+      int keep_q = q.ctu->transquant_bypass && q.ctu->transquant_bypass[q.z];
+      filter_luma_segment(c, s, dir == 0 ? 1 : c->w, dir == 0 ? c->w : 1, bs, qp_avg, keep_p, keep_q);
       if (bs == 2 && ((dir == 0 ? x : y) & 15) == 0) {
         int cx = x >> 1, cy = y >> 1;
-        filter_chroma_segment(c, c->rec[1] + cy * c->cw + cx, dir == 0 ? 1 : c->cw, dir == 0 ? c->cw : 1, qp_avg, c->pp->cb_qp_offset_pps);
-        filter_chroma_segment(c, c->rec[2] + cy * c->cw + cx, dir == 0 ? 1 : c->cw, dir == 0 ? c->cw : 1, qp_avg, c->pp->cr_qp_offset_pps);
+        filter_chroma_segment(c, c->rec[1] + cy * c->cw + cx, dir == 0 ? 1 : c->cw, dir == 0 ? c->cw : 1, qp_avg, c->pp->cb_qp_offset_pps, keep_p, keep_q);
+        filter_chroma_segment(c, c->rec[2] + cy * c->cw + cx, dir == 0 ? 1 : c->cw, dir == 0 ? c->cw : 1, qp_avg, c->pp->cr_qp_offset_pps, keep_p, keep_q);
       }
     }
   }
@@ -924,6 +930,20 @@ int hevcref_reconstruct(hevcref_ctx *c, const hevcrecon_pic_params *pp, const he
     if (!(comp ? pp->sao_chroma : pp->sao_luma)) continue;
     for (int a = 0; a < nctu; a++) sao_ctu(c, &ctus[a], comp, (a % c->ctus_w) * 64, (a / c->ctus_w) * 64, c->rec[comp], dst->p[comp]);
   }
+  /* TComSampleAdaptiveOffset::PCMLFDisableProcess / xPCMRestoration, TLibCommon/TComSampleAdaptiveOffset.cpp:1385-1515,
+   * called after SAO (TLibDecoder/TDecGop.cpp:200): lossless coding units get their reconstruction back (the
+   * reference keeps it in the CU's PCM buffer, TDecCu::xFillPCMBuffer, TLibDecoder/TDecCu.cpp:879-915) */
+  if (pp->sao_luma || pp->sao_chroma)
+    for (int y = 0; y < c->h; y += 4)
+      for (int x = 0; x < c->w; x += 4) {
+        PartRef r = part_at(c, x, y);
+        if (!(r.ctu->transquant_bypass && r.ctu->transquant_bypass[r.z])) continue;
+        for (int j = 0; j < 4; j++)
+          for (int i = 0; i < 4; i++) dst->p[0][(y + j) * c->w + x + i] = c->stage[0][0][(y + j) * c->w + x + i];
+        for (int comp = 1; comp < 3; comp++)
+          for (int j = 0; j < 2; j++)
+            for (int i = 0; i < 2; i++) dst->p[comp][(y / 2 + j) * c->cw + x / 2 + i] = c->stage[0][comp][(y / 2 + j) * c->cw + x / 2 + i];
+      }
   dst->poc = pp->poc;
   return 0;
 }

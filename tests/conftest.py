@@ -9,7 +9,8 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # "scalinglist": encoder_randomaccess_main.cfg with --ScalingList=1 (default scaling lists)
-STREAMS_240 = ["lowdelay_P_main", "randomaccess_main", "randomaccess_he10", "intra_main", "scalinglist"]
+# "lossless": encoder_lowdelay_P_main.cfg, 6 frames, --TransquantBypassEnableFlag=1 --CUTransquantBypassFlagValue=1
+STREAMS_240 = ["lowdelay_P_main", "randomaccess_main", "randomaccess_he10", "intra_main", "scalinglist", "lossless"]
 
 
 def pytest_configure(config):

@@ -25,7 +25,7 @@ def test_oracle_matches_reference_all_stages(stream):
     bd = bit_depths(seq)
     ref = RefModel(seq.seq_params)
     hm = json.load(open(os.path.join(GOLDEN, "hm_md5.json")))[stream + "_240"]
-    assert len(hm) == len(seq.pictures) == 9
+    assert len(hm) == len(seq.pictures) == (6 if stream == "lossless" else 9)
     for pic, (poc, my, mu, mv) in zip(seq.pictures, hm):
         assert pic.poc == poc
         ref.reconstruct(pic)
