@@ -1418,10 +1418,29 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
     const int step = DIR == 0 ? 1 : s.stride_y, line = DIR == 0 ? s.stride_y : 1;
     pel_t *sp = (pel_t *)J.rec[0] + (size_t)y * s.stride_y + x;
     int m[4][8];  // m[k][0..3] = p3..p0, m[k][4..7] = q0..q3 of line k
+    if constexpr (sizeof(pel_t) == 1) {
+      // byte planes: the 4x8 (8x4) samples around the segment as aligned dwords (x is a multiple of 4)
+      if (DIR == 0) {
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+        for (int k = 0; k < 4; k++) {
+          const unsigned lo = *(const unsigned *)(sp + k * line - 4), hi = *(const unsigned *)(sp + k * line);
 #pragma unroll
-      for (int i = 0; i < 8; i++) m[k][i] = sp[k * line + (i - 4) * step];
+          for (int i = 0; i < 4; i++) m[k][i] = (lo >> (8 * i)) & 255, m[k][4 + i] = (hi >> (8 * i)) & 255;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const unsigned w = *(const unsigned *)(sp + (i - 4) * step);
+#pragma unroll
+          for (int k = 0; k < 4; k++) m[k][i] = (w >> (8 * k)) & 255;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) m[k][i] = sp[k * line + (i - 4) * step];
+    }
     const int dp0 = iabs(m[0][1] - 2 * m[0][2] + m[0][3]), dq0 = iabs(m[0][4] - 2 * m[0][5] + m[0][6]);
     const int dp3 = iabs(m[3][1] - 2 * m[3][2] + m[3][3]), dq3 = iabs(m[3][4] - 2 * m[3][5] + m[3][6]);
     const int d0 = dp0 + dq0, d3 = dp3 + dq3, d = d0 + d3;
@@ -1433,20 +1452,22 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
       const bool sw3 = iabs(m[3][0] - m[3][3]) + iabs(m[3][7] - m[3][4]) < (beta >> 3) && 2 * d3 < (beta >> 2) &&
                        iabs(m[3][3] - m[3][4]) < ((tc * 5 + 1) >> 1);
       const bool sw = sw0 && sw3;
+      int r[4][8];  // results; r[k][0] and r[k][7] (p3, q3) never change
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int m0 = m[k][0], m1 = m[k][1], m2 = m[k][2], m3 = m[k][3], m4 = m[k][4], m5 = m[k][5], m6 = m[k][6], m7 = m[k][7];
-        pel_t *o = sp + k * line;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r[k][i] = m[k][i];
         if (sw) {
           if (!keep_p) {
-            o[-step] = (pel_t)clip3i(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
-            o[-2 * step] = (pel_t)clip3i(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
-            o[-3 * step] = (pel_t)clip3i(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
+            r[k][3] = clip3i(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
+            r[k][2] = clip3i(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
+            r[k][1] = clip3i(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
           }
           if (!keep_q) {
-            o[0] = (pel_t)clip3i(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
-            o[step] = (pel_t)clip3i(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
-            o[2 * step] = (pel_t)clip3i(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
+            r[k][4] = clip3i(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
+            r[k][5] = clip3i(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
+            r[k][6] = clip3i(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
           }
         } else {
           int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
@@ -1454,15 +1475,36 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
             delta = clip3i(-tc, tc, delta);
             const int tc2 = tc >> 1;
             if (!keep_p) {
-              o[-step] = (pel_t)clip3i(0, maxv, m3 + delta);
-              if (fp) o[-2 * step] = (pel_t)clip3i(0, maxv, m2 + clip3i(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)));
+              r[k][3] = clip3i(0, maxv, m3 + delta);
+              if (fp) r[k][2] = clip3i(0, maxv, m2 + clip3i(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)));
             }
             if (!keep_q) {
-              o[0] = (pel_t)clip3i(0, maxv, m4 - delta);
-              if (fq) o[step] = (pel_t)clip3i(0, maxv, m5 + clip3i(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
+              r[k][4] = clip3i(0, maxv, m4 - delta);
+              if (fq) r[k][5] = clip3i(0, maxv, m5 + clip3i(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
             }
           }
         }
+      }
+      // write back.  Samples p3 / q3 and, for byte planes, whole dwords are rewritten with their old values where
+      // nothing changed: no other segment of this pass touches them (edges are 8 samples apart and change at most 3
+      // samples on either side), so this is not a race.
+      if constexpr (sizeof(pel_t) == 1) {
+        if (DIR == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            *(unsigned *)(sp + k * line - 4) = pack4(r[k][0], r[k][1], r[k][2], r[k][3]);
+            *(unsigned *)(sp + k * line) = pack4(r[k][4], r[k][5], r[k][6], r[k][7]);
+          }
+        } else {
+#pragma unroll
+          for (int i = 1; i < 7; i++) *(unsigned *)(sp + (i - 4) * step) = pack4(r[0][i], r[1][i], r[2][i], r[3][i]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+          for (int i = 1; i < 7; i++)
+            if (r[k][i] != m[k][i]) sp[k * line + (i - 4) * step] = (pel_t)r[k][i];
       }
     }
   }
