@@ -25,7 +25,10 @@ class SeqParams(C.Structure):
         ("ctu_size", C.c_int32),
         ("max_cu_depth", C.c_int32),
         ("strong_intra_smoothing", C.c_int32),
-        ("reserved", C.c_int32 * 9),
+        ("pcm_bit_depth_luma", C.c_int32),
+        ("pcm_bit_depth_chroma", C.c_int32),
+        ("pcm_loop_filter_disable", C.c_int32),
+        ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -67,6 +70,7 @@ class CtuSyntax(C.Structure):
         ("sao_type", C.c_int32 * 3),
         ("sao_subtype", C.c_int32 * 3),
         ("sao_offset", (C.c_int32 * 4) * 3),
+        ("pcm", C.c_void_p * 3),
     ]
 
 

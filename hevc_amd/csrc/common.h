@@ -26,7 +26,7 @@
 #define P4_DEPTH_MASK 0x03
 #define P4_INTRA 0x04
 #define P4_PARTSIZE_SHIFT 3 /* 3 bits */
-#define P4_BYPASS 0x40
+#define P4_BYPASS 0x40 /* no in-loop filtering: lossless coding unit, or IPCM unit of a sequence with pcm_loop_filter_disable */
 #define P4_IPCM 0x80
 // Part4.tu
 #define P4_TRIDX_MASK 0x03
@@ -48,6 +48,7 @@ struct __attribute__((aligned(16))) Part4 {
 #define TU_DST 0x02
 #define TU_TO_RESI 0x04 /* intra block: write the residual to the residual planes, else add it to the picture */
 #define TU_BYPASS 0x08 /* lossless coding unit: the coefficients ARE the residual */
+#define TU_PCM 0x10    /* IPCM coding unit: the "coefficients" are the PCM samples, stored as they are (shifted up to the bit depth) */
 
 struct TuItem {
   uint16_t x, y;     /* block position in its component plane */
@@ -117,6 +118,8 @@ struct SeqInfo {
   int32_t bd_y, bd_c;
   int32_t strong_intra;
   int32_t stride_y, stride_c; /* plane strides in samples */
+  int32_t pcm_bd_y, pcm_bd_c; /* bit depth of IPCM samples */
+  int32_t pcm_lf_disable;     /* IPCM units are left alone by deblocking and SAO */
 };
 
 // Per-picture job descriptor, read by every kernel through a device array indexed by the
@@ -147,7 +150,8 @@ struct PicJob {
   int32_t cb_off_pps, cr_off_pps; /* deblocking uses the PPS offsets only */
   int32_t cb_off, cr_off;         /* PPS offset + slice delta, for de-quantisation */
   int32_t sao_luma, sao_chroma;
-  int32_t has_bypass; /* some coding unit is lossless: SAO has to leave its samples alone */
+  int32_t has_bypass; /* some coding unit is exempt from in-loop filtering: SAO has to leave its samples alone */
+  int32_t has_pcm;    /* some coding unit is IPCM: its samples are in the picture before the intra kernel runs */
   int32_t *error_flag;
 };
 

@@ -107,6 +107,9 @@ SeqInfo make_seq_info(const hevcrecon_seq_params &sp) {
   s.strong_intra = sp.strong_intra_smoothing;
   s.stride_y = (sp.width + 127) & ~127;
   s.stride_c = (sp.width / 2 + 127) & ~127;
+  s.pcm_bd_y = sp.pcm_bit_depth_luma;
+  s.pcm_bd_c = sp.pcm_bit_depth_chroma;
+  s.pcm_lf_disable = sp.pcm_loop_filter_disable;
   return s;
 }
 
@@ -122,6 +125,11 @@ bool seq_params_ok(const hevcrecon_seq_params &sp, std::string &why) {
   if (sp.bit_depth_luma < 8 || sp.bit_depth_luma > 12 || sp.bit_depth_chroma < 8 || sp.bit_depth_chroma > 12 ||
       (sp.bit_depth_luma > 8) != (sp.bit_depth_chroma > 8)) {
     why = "bit depths must be 8..12 and on the same side of 8 for luma and chroma";
+    return false;
+  }
+  if (sp.pcm_bit_depth_luma < 0 || sp.pcm_bit_depth_luma > sp.bit_depth_luma || sp.pcm_bit_depth_chroma < 0 ||
+      sp.pcm_bit_depth_chroma > sp.bit_depth_chroma) {
+    why = "PCM bit depths must not exceed the sample bit depths";
     return false;
   }
   return true;
@@ -601,6 +609,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     j.sao_luma = k.pp.sao_luma;
     j.sao_chroma = k.pp.sao_chroma;
     j.has_bypass = k.has_bypass ? 1 : 0;
+    j.has_pcm = k.has_pcm ? 1 : 0;
     j.error_flag = c->error_flag_dev;
     any_deblock = any_deblock || !k.pp.deblocking_disable;
   }

@@ -830,7 +830,9 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
   const int16_t *coef = J.coeff + it.coeff_off;
   const bool tskip = (it.flags & TU_TSKIP) != 0;
   // lossless coding unit (TComTrQuant::invtransformNxN, TLibCommon/TComTrQuant.cpp:1269-1279): residual = coefficients
-  const bool bypass = (it.flags & TU_BYPASS) != 0;
+  // IPCM coding unit (TDecCu::xDecodePCMTexture, TLibDecoder/TDecCu.cpp:798-837): the block holds samples, not coefficients
+  const bool pcm = (it.flags & TU_PCM) != 0;
+  const bool bypass = (it.flags & (TU_BYPASS | TU_PCM)) != 0;
   const bool dst4 = LOG2N == 2 && (it.flags & TU_DST);
 
   // ---- pass 1 (columns) ----
@@ -906,8 +908,9 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
     }
   }
   if (bypass) {
+    const int up = pcm ? bd - (comp ? s.pcm_bd_c : s.pcm_bd_y) : 0;
 #pragma unroll
-    for (int x = 0; x < N; x++) res[x] = row[x];
+    for (int x = 0; x < N; x++) res[x] = row[x] << up;
   } else if (tskip) {
     const int ts = 15 - bd - LOG2N;  // > 0 for every supported bit depth
 #pragma unroll
@@ -922,6 +925,10 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
     int16_t *o = J.resi[comp] + (size_t)(it.y + y) * (comp ? s.stride_c : s.stride_y) + it.x;
 #pragma unroll
     for (int x = 0; x < N; x++) o[x] = (int16_t)res[x];
+  } else if (pcm) {
+    pel_t *o = (pel_t *)J.rec[comp] + (size_t)(it.y + y) * (comp ? s.stride_c : s.stride_y) + it.x;
+#pragma unroll
+    for (int x = 0; x < N; x++) o[x] = (pel_t)res[x];
   } else {
     // TDecCu::xReconInter / TComYuv::addClip (TLibDecoder/TDecCu.cpp:468-486, TLibCommon/TComYuv.cpp:401-459):
     // adding a zero residual is the identity, so only coded blocks need touching.
@@ -984,7 +991,8 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
 
   // ---- stage the CTU and its top / left borders in LDS ----
   // An all-intra picture writes every sample of the CTU before reading it, so only the borders are needed.
-  const bool need_inside = J.slice_type != 2;
+  // (IPCM units are the exception: the transform kernel has already stored them)
+  const bool need_inside = J.slice_type != 2 || J.has_pcm;
   {
     // All loads of the staging phase are independent of each other (one round trip to memory in total):
     // interior rows as 16-byte vectors, the border row and column as single samples.

@@ -55,6 +55,7 @@ void PackedPicture::begin(const SeqInfo &s) {
   lvl_c.assign((size_t)s.uw * s.uh, 0);
   use_scaling = false;
   has_bypass = false;
+  has_pcm = false;
   mc_ref_samples = 0;
   max_ref_idx[0] = max_ref_idx[1] = -1;
   inter_without_ref = false;
@@ -130,13 +131,16 @@ void PackedPicture::walk_cu(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy,
   }
   const int np = (size >> 2) * (size >> 2);
   const bool intra = ctu->pred_mode[z] == 1;
+  const bool pcm = intra && ctu->ipcm && ctu->ipcm[z];
+  // TComLoopFilter::xEdgeFilterLuma (TLibCommon/TComLoopFilter.cpp:633-641) and xPCMCURestoration
+  // (TLibCommon/TComSampleAdaptiveOffset.cpp:1435): lossless units always, IPCM units when the SPS says so
+  const bool unfiltered = (ctu->transquant_bypass && ctu->transquant_bypass[z]) || (pcm && seq.pcm_lf_disable);
   for (int zz = z; zz < z + np; zz++) {
     const int ux = (ctux >> 2) + kZ.x[zz], uy = (ctuy >> 2) + kZ.y[zz];
     Part4 &p = rec4[(size_t)uy * seq.uw + ux];
     p.flags = (uint8_t)((ctu->depth[zz] & P4_DEPTH_MASK) | (ctu->pred_mode[zz] == 1 ? P4_INTRA : 0) |
                         ((ctu->part_size[zz] & 7) << P4_PARTSIZE_SHIFT) |
-                        ((ctu->transquant_bypass && ctu->transquant_bypass[zz]) ? P4_BYPASS : 0) |
-                        ((ctu->ipcm && ctu->ipcm[zz]) ? P4_IPCM : 0));
+                        (unfiltered ? P4_BYPASS : 0) | (pcm ? P4_IPCM : 0));
     p.tu = (uint8_t)((ctu->tr_idx[zz] & P4_TRIDX_MASK) | (((ctu->cbf[0][zz] >> ctu->tr_idx[zz]) & 1) ? P4_CBF_Y : 0) | P4_VALID);
     p.qp = ctu->qp[zz];
     for (int l = 0; l < 2; l++) {
@@ -151,11 +155,32 @@ void PackedPicture::walk_cu(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy,
       for (int l = 0; l < 2; l++) max_ref_idx[l] = std::max<int>(max_ref_idx[l], p.ref_idx[l]);
     }
   }
-  if (ctu->ipcm && ctu->ipcm[z]) {
-    error = "IPCM coding units are not supported";
+  if (unfiltered) has_bypass = true;
+  if (pcm) {
+    // TDecCu::xReconPCM (TLibDecoder/TDecCu.cpp:845-871): no prediction, no residual; the samples travel in the
+    // coefficient stream and the transform kernel stores them
+    if (!ctu->pcm[0] || !ctu->pcm[1] || !ctu->pcm[2] || seq.pcm_bd_y <= 0 || seq.pcm_bd_c <= 0 || size > 32) {
+      error = "IPCM coding unit without PCM samples, PCM bit depths, or larger than 32x32";
+      return;
+    }
+    has_pcm = true;
+    for (int comp = 0; comp < 3; comp++) {
+      const int log2n = ilog2(size) - (comp ? 1 : 0), nn = 1 << (2 * log2n);
+      const int16_t *src = ctu->pcm[comp] + (comp ? 4 * z : 16 * z);
+      const size_t off = coeff.size();
+      coeff.insert(coeff.end(), src, src + nn);
+      TuItem t;
+      std::memset(&t, 0, sizeof(t));
+      t.x = (uint16_t)(comp ? x >> 1 : x);
+      t.y = (uint16_t)(comp ? y >> 1 : y);
+      t.comp = (uint8_t)comp;
+      t.flags = TU_PCM;
+      t.qp = ctu->qp[z];
+      t.coeff_off = (uint32_t)off;
+      tu[log2n - 2].push_back(t);
+    }
     return;
   }
-  if (ctu->transquant_bypass && ctu->transquant_bypass[z]) has_bypass = true;
   if (intra) {
     // TDecCu::xReconIntraQT, TLibDecoder/TDecCu.cpp:652-674: all luma blocks of the CU, then all chroma blocks.
     const int parts = ctu->part_size[z] == 3 ? 4 : 1;

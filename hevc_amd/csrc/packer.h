@@ -22,7 +22,8 @@ struct PackedPicture {
   std::vector<SaoCtu> sao;
   std::vector<McTile> mc_tile[3];   // filled by finish(): 64x64 / 32x32 / 16x16 regions predicted as one block
   std::vector<McBlk> mc_blk;        // filled by finish(): 16x16 regions predicted unit by unit
-  bool has_bypass;                  // some coding unit is lossless (cu_transquant_bypass)
+  bool has_bypass;                  // some coding unit is exempt from in-loop filtering (lossless, or IPCM with the filters off)
+  bool has_pcm;                     // some coding unit is IPCM
   bool use_scaling;                 // the picture de-quantises with `scaling`
   ScalingTables scaling;
   int max_ref_idx[2];               // largest reference index used by an inter block, per list (-1: none)

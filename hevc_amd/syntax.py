@@ -22,6 +22,8 @@ from . import abi
 MAGIC = b"HVSYN1\0\0"
 PICT = 0x54434950
 SCAL = 0x4C414353  # optional record before a picture: the scaling lists it de-quantises with
+PCMS = 0x534D4350  # optional record before a picture: PCM sample arrays of the CTUs that hold IPCM units
+_PCM_CTU_BYTES = 4 + (16 + 4 + 4) * abi.PARTS_PER_CTU * 2
 P = abi.PARTS_PER_CTU
 
 # (name, dtype, elements per partition, count) in file order
@@ -52,6 +54,7 @@ class PictureSyntax:
         self.a = {}          # name -> array
         self.sao = None      # (nctu, 3, 6) int32: type, subtype, offset[4]
         self.scaling = None  # abi.ScalingLists when the picture uses scaling lists
+        self.pcm = {}        # ctu address -> (y, cb, cr) int16 arrays, for the CTUs that hold IPCM units
         self.stage_md5 = None  # (3, 3) hex strings: [stage][component]
         self.planes = None   # optional [stage][component] 2-D uint16
         self._keep = None
@@ -86,6 +89,7 @@ class PictureSyntax:
                 s.cbf[c] = ptr(a["cbf%d" % c], i)
                 s.transform_skip[c] = ptr(a["tskip%d" % c], i)
                 s.coeff[c] = ptr(coeff32[c], i)
+                s.pcm[c] = self.pcm[i][c].ctypes.data if i in self.pcm else None
                 s.sao_type[c] = int(self.sao[i, c, 0])
                 s.sao_subtype[c] = int(self.sao[i, c, 1])
                 for k in range(4):
@@ -133,9 +137,15 @@ def read_dump(path, max_pictures=None):
                 break
             tag, nctu, pic_id, has_planes = struct.unpack("<4i", hdr)
             scaling = None
-            if tag == SCAL:
-                # the 16 bytes just read are the record's tag + 12 bytes of padding
-                scaling = abi.ScalingLists.from_buffer_copy(f.read(C.sizeof(abi.ScalingLists)))
+            pcm = {}
+            while tag in (SCAL, PCMS):
+                if tag == SCAL:
+                    # the 16 bytes just read are the record's tag + 12 bytes of padding
+                    scaling = abi.ScalingLists.from_buffer_copy(f.read(C.sizeof(abi.ScalingLists)))
+                else:
+                    for _ in range(nctu):  # second header word: number of CTUs in the record
+                        addr = struct.unpack("<i", f.read(4))[0]
+                        pcm[addr] = tuple(np.frombuffer(f.read(n * P * 2), dtype=np.int16).copy() for n in (16, 4, 4))
                 hdr = f.read(16)
                 tag, nctu, pic_id, has_planes = struct.unpack("<4i", hdr)
             if tag != PICT:
@@ -143,6 +153,7 @@ def read_dump(path, max_pictures=None):
             pic = PictureSyntax()
             pic.nctu, pic.pic_id = nctu, pic_id
             pic.scaling = scaling
+            pic.pcm = pcm
             raw = f.read(C.sizeof(abi.PicParams))
             C.memmove(C.addressof(pic.pic_params), raw, len(raw))
 
@@ -192,6 +203,10 @@ def strip_planes_and_compress(src, dst, preset=6):
             if tag == SCAL:  # optional scaling-list record: copied as it is
                 out.write(hdr)
                 out.write(f.read(C.sizeof(abi.ScalingLists)))
+                continue
+            if tag == PCMS:
+                out.write(hdr)
+                out.write(f.read(nctu * _PCM_CTU_BYTES))
                 continue
             body = C.sizeof(abi.PicParams) + nctu * (len(_U8_FIELDS) * P + 2 * 4 * P + 2 * P + 2 * P + (16 + 4 + 4) * P * 2 + 18 * 4) + 144
             out.write(struct.pack("<4i", tag, nctu, pic_id, 0))

@@ -49,7 +49,11 @@ typedef struct hevcrecon_seq_params {
   int32_t ctu_size;               /* 64 */
   int32_t max_cu_depth;           /* g_uiMaxCUDepth incl. g_uiAddCUDepth: ctu_size >> max_cu_depth == 4 */
   int32_t strong_intra_smoothing; /* sps->getUseStrongIntraSmoothing() */
-  int32_t reserved[9];
+  /* IPCM coding units (TDecCu::xReconPCM, TLibDecoder/TDecCu.cpp:845-871); all zero when the SPS has PCM off */
+  int32_t pcm_bit_depth_luma;      /* sps->getPCMBitDepthLuma() */
+  int32_t pcm_bit_depth_chroma;    /* sps->getPCMBitDepthChroma() */
+  int32_t pcm_loop_filter_disable; /* sps->getUsePCM() && sps->getPCMFilterDisableFlag() */
+  int32_t reserved[6];
 } hevcrecon_seq_params;
 
 /* Picture/slice-level parameters (one slice per picture).
@@ -98,6 +102,9 @@ typedef struct hevcrecon_ctu_syntax {
   int32_t sao_type[3];
   int32_t sao_subtype[3];
   int32_t sao_offset[3][4];
+  /* TComDataCU::getPCMSampleY/Cb/Cr (Pel arrays laid out like coeff[]: offset 16*absPartIdx luma, 4*absPartIdx
+   * chroma, raster inside the coding unit); read only for partitions whose ipcm flag is set; may be NULL */
+  const int16_t *pcm[3];
 } hevcrecon_ctu_syntax;
 
 /* Scaling lists in effect for a picture: the TComScalingList that TDecTop::xDecodeSlice has resolved from

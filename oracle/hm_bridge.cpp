@@ -136,6 +136,11 @@ struct Bridge {
     sp.ctu_size = g_uiMaxCUWidth;
     sp.max_cu_depth = g_uiMaxCUDepth;
     sp.strong_intra_smoothing = sl->getSPS()->getUseStrongIntraSmoothing();
+    if (sl->getSPS()->getUsePCM()) {
+      sp.pcm_bit_depth_luma = sl->getSPS()->getPCMBitDepthLuma();
+      sp.pcm_bit_depth_chroma = sl->getSPS()->getPCMBitDepthChroma();
+      sp.pcm_loop_filter_disable = sl->getSPS()->getPCMFilterDisableFlag();
+    }
   }
 
   void fill_pic(TComPic *pic, hevcrecon_pic_params &pp) {
@@ -202,6 +207,9 @@ struct Bridge {
     cs.coeff[0] = cu->getCoeffY();
     cs.coeff[1] = cu->getCoeffCb();
     cs.coeff[2] = cu->getCoeffCr();
+    cs.pcm[0] = cu->getPCMSampleY();
+    cs.pcm[1] = cu->getPCMSampleCb();
+    cs.pcm[2] = cu->getPCMSampleCr();
     for (int l = 0; l < 2; l++) {
       TComCUMvField *f = cu->getCUMvField(RefPicList(l));
       cs.mv[l] = (const int16_t *)&f->getMv(0);
@@ -266,13 +274,32 @@ struct Bridge {
       put(shdr, 4);
       put(&sl, 1);
     }
-    int32_t hdr[4] = {0x54434950 /* "PICT" */, nctu, pic_id(pic), dump_planes ? 1 : 0};
-    put(hdr, 4);
-    put(&pp, 1);
     std::vector<hevcrecon_ctu_syntax> cs(nctu);
     std::vector<int8_t> refbuf(nctu * 2 * HEVCRECON_PARTS_PER_CTU);
     for (int a = 0; a < nctu; a++) fill_ctu(pic, a, pp, cs[a], &refbuf[a * 2 * HEVCRECON_PARTS_PER_CTU]);
     const int P = HEVCRECON_PARTS_PER_CTU;
+    {  // optional record in front of the picture: the PCM sample arrays of the CTUs that hold IPCM units
+      std::vector<int32_t> with_pcm;
+      for (int a = 0; a < nctu; a++) {
+        bool any = false;
+        for (int z = 0; z < P && !any; z++) any = cs[a].ipcm[z] != 0;
+        if (any) with_pcm.push_back(a);
+      }
+      if (!with_pcm.empty()) {
+        int32_t phdr[4] = {0x534D4350 /* "PCMS" */, (int32_t)with_pcm.size(), 0, 0};
+        put(phdr, 4);
+        for (size_t i = 0; i < with_pcm.size(); i++) {
+          const int a = with_pcm[i];
+          put(&with_pcm[i], 1);
+          put(cs[a].pcm[0], 16 * P);
+          put(cs[a].pcm[1], 4 * P);
+          put(cs[a].pcm[2], 4 * P);
+        }
+      }
+    }
+    int32_t hdr[4] = {0x54434950 /* "PICT" */, nctu, pic_id(pic), dump_planes ? 1 : 0};
+    put(hdr, 4);
+    put(&pp, 1);
     for (int a = 0; a < nctu; a++) put(cs[a].depth, P);
     for (int a = 0; a < nctu; a++) put(cs[a].pred_mode, P);
     for (int a = 0; a < nctu; a++) put(cs[a].part_size, P);

@@ -155,6 +155,13 @@ static Pic *get_pic(hevcref_ctx *c, int id) {
 static inline int plane_w(const hevcref_ctx *c, int comp) { return comp ? c->cw : c->w; }
 static inline int plane_h(const hevcref_ctx *c, int comp) { return comp ? c->ch : c->h; }
 static inline int bit_depth(const hevcref_ctx *c, int comp) { return comp ? c->sp.bit_depth_chroma : c->sp.bit_depth_luma; }
+/* Units the in-loop filters leave alone: lossless ones (TComDataCU::isLosslessCoded, TLibCommon/TComDataCU.cpp:1703-1706;
+ * the CU flag is only ever set when the PPS enables it) and IPCM ones when the SPS switches their filtering off
+ * (bPCMFilter, TLibCommon/TComLoopFilter.cpp:562,633-641; TLibCommon/TComSampleAdaptiveOffset.cpp:1396,1435). */
+static inline int unfiltered(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int z) {
+  if (ctu->transquant_bypass && ctu->transquant_bypass[z]) return 1;
+  return c->sp.pcm_loop_filter_disable && ctu->ipcm && ctu->ipcm[z];
+}
 
 /* z index of the partition that holds luma sample (x,y) of CTU-relative coordinates */
 static inline int zidx(const hevcref_ctx *c, int x, int y) { return c->raster_to_z[y >> 2][x >> 2]; }
@@ -640,7 +647,18 @@ static void decompress_cu(hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int c
     return;
   }
   if (ctu->pred_mode[z] == 1) {
-    if (ctu->ipcm && ctu->ipcm[z]) return; /* IPCM is not part of this restatement */
+    if (ctu->ipcm && ctu->ipcm[z]) {
+      /* TDecCu::xReconPCM / xDecodePCMTexture, TLibDecoder/TDecCu.cpp:798-871: the CU's PCM samples (offset
+       * 16*z luma, 4*z chroma, raster inside the CU) shifted up to the sample bit depth */
+      for (int comp = 0; comp < 3; comp++) {
+        int sh = comp ? 1 : 0, n = size >> sh, pw = plane_w(c, comp);
+        int up = bit_depth(c, comp) - (comp ? c->sp.pcm_bit_depth_chroma : c->sp.pcm_bit_depth_luma);
+        const int16_t *src = ctu->pcm[comp] + (comp ? 4 * z : 16 * z);
+        for (int j = 0; j < n; j++)
+          for (int i = 0; i < n; i++) c->rec[comp][((y >> sh) + j) * pw + (x >> sh) + i] = (int16_t)(src[j * n + i] << up);
+      }
+      return;
+    }
     int parts = ctu->part_size[z] == 3 ? 4 : 1; /* TDecCu::xReconIntraQT, TLibDecoder/TDecCu.cpp:652-674 */
     int init = parts == 4 ? 1 : 0;
     int np = (size >> 2) * (size >> 2) / 4;
@@ -845,9 +863,7 @@ static void deblock_cu(hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int ctux
       PartRef p = dir == 0 ? part_at(c, x - 1, y) : part_at(c, x, y - 1);
       int qp_avg = (p.ctu->qp[p.z] + q.ctu->qp[q.z] + 1) >> 1;
       int16_t *s = c->rec[0] + y * c->w + x;
-      /* TComDataCU::isLosslessCoded, TLibCommon/TComDataCU.cpp:1703-1706 (the CU flag is only ever set when the PPS enables it) */
-      int keep_p = p.ctu->transquant_bypass && p.ctu->transquant_bypass[p.z];
-      int keep_q = q.ctu->transquant_bypass && q.ctu->transquant_bypass[q.z];
+      int keep_p = unfiltered(c, p.ctu, p.z), keep_q = unfiltered(c, q.ctu, q.z);
       filter_luma_segment(c, s, dir == 0 ? 1 : c->w, dir == 0 ? c->w : 1, bs, qp_avg, keep_p, keep_q);
       if (bs == 2 && ((dir == 0 ? x : y) & 15) == 0) {
         int cx = x >> 1, cy = y >> 1;
@@ -931,13 +947,13 @@ int hevcref_reconstruct(hevcref_ctx *c, const hevcrecon_pic_params *pp, const he
     for (int a = 0; a < nctu; a++) sao_ctu(c, &ctus[a], comp, (a % c->ctus_w) * 64, (a / c->ctus_w) * 64, c->rec[comp], dst->p[comp]);
   }
   /* TComSampleAdaptiveOffset::PCMLFDisableProcess / xPCMRestoration, TLibCommon/TComSampleAdaptiveOffset.cpp:1385-1515,
-   * called after SAO (TLibDecoder/TDecGop.cpp:200): lossless coding units get their reconstruction back (the
+   * called after SAO (TLibDecoder/TDecGop.cpp:200): lossless and unfiltered IPCM units get their reconstruction back (the
    * reference keeps it in the CU's PCM buffer, TDecCu::xFillPCMBuffer, TLibDecoder/TDecCu.cpp:879-915) */
   if (pp->sao_luma || pp->sao_chroma)
     for (int y = 0; y < c->h; y += 4)
       for (int x = 0; x < c->w; x += 4) {
         PartRef r = part_at(c, x, y);
-        if (!(r.ctu->transquant_bypass && r.ctu->transquant_bypass[r.z])) continue;
+        if (!unfiltered(c, r.ctu, r.z)) continue;
         for (int j = 0; j < 4; j++)
           for (int i = 0; i < 4; i++) dst->p[0][(y + j) * c->w + x + i] = c->stage[0][0][(y + j) * c->w + x + i];
         for (int comp = 1; comp < 3; comp++)

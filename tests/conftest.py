@@ -10,7 +10,11 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # "scalinglist": encoder_randomaccess_main.cfg with --ScalingList=1 (default scaling lists)
 # "lossless": encoder_lowdelay_P_main.cfg, 6 frames, --TransquantBypassEnableFlag=1 --CUTransquantBypassFlagValue=1
-STREAMS_240 = ["lowdelay_P_main", "randomaccess_main", "randomaccess_he10", "intra_main", "scalinglist", "lossless"]
+# "pcm": encoder_randomaccess_he10.cfg, 5 frames of the clip with a white-noise patch, QP 6, --PCMEnabledFlag=1
+#        --PCMFilterDisableFlag=1 (10-bit pictures, 8-bit PCM samples, IPCM units exempt from the in-loop filters)
+# "pcmlf": encoder_lowdelay_P_main.cfg, 4 frames of the same clip, QP 6, --PCMEnabledFlag=1 --PCMFilterDisableFlag=0
+STREAMS_240 = ["lowdelay_P_main", "randomaccess_main", "randomaccess_he10", "intra_main", "scalinglist", "lossless", "pcm", "pcmlf"]
+NUM_PICTURES_240 = {"lossless": 6, "pcm": 5, "pcmlf": 4}  # every other stream has 9
 
 
 def pytest_configure(config):

@@ -14,7 +14,7 @@ import os
 
 import pytest
 
-from conftest import GOLDEN, STREAMS_240, bit_depths, load_golden
+from conftest import GOLDEN, NUM_PICTURES_240, STREAMS_240, bit_depths, load_golden
 from hevc_amd import syntax
 from oracle.refmodel import RefModel
 
@@ -25,7 +25,7 @@ def test_oracle_matches_reference_all_stages(stream):
     bd = bit_depths(seq)
     ref = RefModel(seq.seq_params)
     hm = json.load(open(os.path.join(GOLDEN, "hm_md5.json")))[stream + "_240"]
-    assert len(hm) == len(seq.pictures) == (6 if stream == "lossless" else 9)
+    assert len(hm) == len(seq.pictures) == NUM_PICTURES_240.get(stream, 9)
     for pic, (poc, my, mu, mv) in zip(seq.pictures, hm):
         assert pic.poc == poc
         ref.reconstruct(pic)

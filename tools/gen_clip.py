@@ -7,7 +7,9 @@ residuals are exercised) and smooth chroma waves.  Whole-pixel motion is
 avoided on purpose: it would yield almost only integer motion vectors and the
 8-tap / 4-tap interpolation filters would hardly run.
 
-usage: gen_clip.py WIDTH HEIGHT FRAMES SEED OUT.yuv
+usage: gen_clip.py WIDTH HEIGHT FRAMES SEED OUT.yuv [noise]
+With "noise" a 104x88 patch of white noise (all three planes) is pasted at luma (36, 44) of every frame:
+incompressible content, for which an encoder with PCM enabled picks IPCM coding units at low QP.
 """
 import sys
 import numpy as np
@@ -34,8 +36,9 @@ def _bilinear(tex, yy, xx):
             + fy * ((1 - fx) * tex[y1, x0] + fx * tex[y1, x1]))
 
 
-def frames(width, height, nframes, seed):
+def frames(width, height, nframes, seed, noise=False):
     rng = np.random.default_rng(seed)
+    nrng = np.random.default_rng(seed + 1)
     tex = _box3(rng.integers(0, 256, (2 * height, 2 * width)).astype(np.float32))
     # stretch contrast back after the box filters
     tex = (tex - tex.mean()) * 4.0 + 128.0
@@ -52,13 +55,18 @@ def frames(width, height, nframes, seed):
         luma[py:py + oh, px:px + ow] = _bilinear(tex, oy - 0.75 * t + 300, ox - 1.25 * t + 500)
         cb = 128 + 20 * np.sin((cx + 1.5 * t) / 17.0)
         cr = 128 + 30 * np.cos((cy + 0.75 * t) / 11.0)
-        yield tuple(np.clip(np.rint(p), 0, 255).astype(np.uint8) for p in (luma, cb, cr))
+        planes = [np.clip(np.rint(p), 0, 255).astype(np.uint8) for p in (luma, cb, cr)]
+        if noise:
+            planes[0][44:132, 36:140] = nrng.integers(0, 256, (88, 104))
+            planes[1][22:66, 18:70] = nrng.integers(0, 256, (44, 52))
+            planes[2][22:66, 18:70] = nrng.integers(0, 256, (44, 52))
+        yield tuple(planes)
 
 
 def main():
     w, h, n, seed = (int(a) for a in sys.argv[1:5])
     with open(sys.argv[5], "wb") as f:
-        for planes in frames(w, h, n, seed):
+        for planes in frames(w, h, n, seed, noise=len(sys.argv) > 6 and sys.argv[6] == "noise"):
             for p in planes:
                 f.write(p.tobytes())
 
