@@ -85,6 +85,14 @@ class ScalingLists(C.Structure):
     ]
 
 
+class PredWeights(C.Structure):
+    _fields_ = [
+        ("log2_denom", ((C.c_int16 * 3) * MAX_REFS) * 2),
+        ("weight", ((C.c_int16 * 3) * MAX_REFS) * 2),
+        ("offset", ((C.c_int16 * 3) * MAX_REFS) * 2),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/hevcrecon.h declares
 _P = C.c_void_p
 _I16P = C.c_void_p
@@ -99,6 +107,7 @@ EXPORTS = {
     "hevcrecon_syntax_destroy": (None, [_P]),
     "hevcrecon_syntax_begin": (C.c_int, [_P]),
     "hevcrecon_syntax_set_scaling_lists": (C.c_int, [_P, C.c_void_p]),
+    "hevcrecon_syntax_set_pred_weights": (C.c_int, [_P, C.c_void_p]),
     "hevcrecon_syntax_add_ctu": (C.c_int, [_P, C.c_int, C.POINTER(CtuSyntax)]),
     "hevcrecon_syntax_finish": (C.c_int, [_P, C.POINTER(PicParams)]),
     "hevcrecon_reconstruct": (C.c_int, [_P, _P, C.c_int]),

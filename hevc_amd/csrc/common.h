@@ -104,6 +104,13 @@ struct ScalingTables {
   uint8_t dc32[2];
 };
 
+// Explicit weighted prediction of a picture (same content as hevcrecon_pred_weights): [list][reference index][component]
+struct WpTables {
+  int16_t log2d[2][HR_MAX_REFS][3];
+  int16_t w[2][HR_MAX_REFS][3];
+  int16_t o[2][HR_MAX_REFS][3];
+};
+
 struct SaoCtu {
   int8_t type; /* -1 off, 0..3 edge classes, 4 band */
   int8_t band; /* band position */
@@ -145,6 +152,7 @@ struct PicJob {
   int32_t n_waves;
   const SaoCtu *sao;
   const ScalingTables *scaling; /* NULL: flat de-quantisation */
+  const WpTables *wp;           /* NULL: default (un)weighted prediction */
   int32_t slice_type; /* 0 B, 1 P, 2 I */
   int32_t deblock_disable, beta_off_div2, tc_off_div2;
   int32_t cb_off_pps, cr_off_pps; /* deblocking uses the PPS offsets only */

@@ -75,7 +75,7 @@ struct hevcrecon_syntax {
   size_t dev_cap = 0;
   char *host = nullptr;  // pinned staging
   size_t host_cap = 0;
-  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_mct[3] = {0, 0, 0}, off_mcb = 0, off_scal = 0;
+  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_mct[3] = {0, 0, 0}, off_mcb = 0, off_scal = 0, off_wp = 0;
   bool uploaded = false;
   std::string err;
 };
@@ -378,6 +378,25 @@ extern "C" int hevcrecon_syntax_set_scaling_lists(hevcrecon_syntax *s, const hev
   return 0;
 }
 
+extern "C" int hevcrecon_syntax_set_pred_weights(hevcrecon_syntax *s, const hevcrecon_pred_weights *w) {
+  if (!s) return 1;
+  static_assert(sizeof(WpTables) == sizeof(hevcrecon_pred_weights), "weight table layouts differ");
+  if (s->pk.finished) return fail(s->ctx, "prediction weights must be set between hevcrecon_syntax_begin and hevcrecon_syntax_finish");
+  if (w) {
+    // what the kernels' 24-bit multiplies and 32-bit sums assume (the syntax allows far less: denominators 0..7,
+    // weights -128..255, offsets -128..127)
+    for (int l = 0; l < 2; l++)
+      for (int r = 0; r < HR_MAX_REFS; r++)
+        for (int c = 0; c < 3; c++)
+          if (w->log2_denom[l][r][c] < 0 || w->log2_denom[l][r][c] > 7 || w->weight[l][r][c] < -256 || w->weight[l][r][c] > 255 ||
+              w->offset[l][r][c] < -128 || w->offset[l][r][c] > 127)
+            return fail(s->ctx, "prediction weight, offset or denominator out of range");
+    std::memcpy(&s->pk.wp, w, sizeof(WpTables));
+  }
+  s->pk.use_wp = w != nullptr;
+  return 0;
+}
+
 extern "C" int hevcrecon_syntax_add_ctu(hevcrecon_syntax *s, int ctu_addr, const hevcrecon_ctu_syntax *ctu) {
   if (!s || !ctu) return 1;
   if (!s->pk.add_ctu(ctu_addr, ctu)) {
@@ -414,6 +433,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   for (int i = 0; i < 3; i++) s->off_mct[i] = place(k.mc_tile[i].size() * sizeof(McTile));
   s->off_mcb = place(k.mc_blk.size() * sizeof(McBlk));
   s->off_scal = place(sizeof(ScalingTables));
+  s->off_wp = place(sizeof(WpTables));
   const size_t upload_bytes = off;
   const size_t total = off;
   if (s->dev_cap < total) {
@@ -444,6 +464,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   for (int i = 0; i < 3; i++) std::memcpy(s->host + s->off_mct[i], k.mc_tile[i].data(), k.mc_tile[i].size() * sizeof(McTile));
   std::memcpy(s->host + s->off_mcb, k.mc_blk.data(), k.mc_blk.size() * sizeof(McBlk));
   std::memcpy(s->host + s->off_scal, &k.scaling, sizeof(ScalingTables));
+  std::memcpy(s->host + s->off_wp, &k.wp, sizeof(WpTables));
   HIPCHK(c, hipMemcpyAsync(s->dev, s->host, upload_bytes, hipMemcpyHostToDevice, c->stream));
   s->uploaded = true;
   return 0;
@@ -553,7 +574,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
   PicJob *jh = c->jobs_host + (size_t)slot * HR_MAX_BATCH;
   PicJob *jd = c->jobs_dev + (size_t)slot * HR_MAX_BATCH;
   int max_tu[4] = {0, 0, 0, 0}, max_levels = 0, max_mct[3] = {0, 0, 0}, max_mcb = 0;
-  bool any_deblock = false, any_sao = false;
+  bool any_deblock = false, any_sao = false, any_wp = false;
   for (int i = 0; i < n; i++) {
     hevcrecon_syntax *y = syn[i];
     const PackedPicture &k = y->pk;
@@ -598,6 +619,8 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     if (j.n_waves > max_levels) max_levels = j.n_waves;
     j.sao = (const SaoCtu *)(y->dev + y->off_sao);
     j.scaling = k.use_scaling ? (const ScalingTables *)(y->dev + y->off_scal) : nullptr;
+    j.wp = k.use_wp ? (const WpTables *)(y->dev + y->off_wp) : nullptr;
+    any_wp = any_wp || k.use_wp;
     j.slice_type = k.pp.slice_type;
     j.deblock_disable = k.pp.deblocking_disable;
     j.beta_off_div2 = k.pp.beta_offset_div2;
@@ -618,13 +641,13 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
   c->ring_used[slot] = true;
   // ---- launches ----
   if (max_mct[0] > 0 || max_mct[1] > 0 || max_mct[2] > 0 || max_mcb > 0) {
-    // arg = 0..2: uniform regions of 64, 32, 16 samples; 3: the mixed rest
+    // arg = 0..2: uniform regions of 64, 32, 16 samples; 3: the mixed rest; +4: the variants with explicit weights
     const int cls[4] = {K_INTER, K_INTER_T32, K_INTER_T16, K_INTER_BLK};
     for (int t = 0; t < 4; t++) {
       const int cnt = t < 3 ? max_mct[t] : max_mcb;
       if (cnt > 0) {
         Timed tm(c, cls[t], 1);
-        hr_launch(K_INTER, jd, n, s, c->stream, t, cnt);
+        hr_launch(K_INTER, jd, n, s, c->stream, t + (any_wp ? 4 : 0), cnt);
       }
     }
   }

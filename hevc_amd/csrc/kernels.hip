@@ -288,8 +288,46 @@ __device__ __forceinline__ void interp_u8_filter(const unsigned w[BH + NT - 1][(
     for (int i = 0; i < BW; i++) out[j][i] = acc[j][i] >> 6;
 }
 
+// Final rounding of a prediction, one component: out = clip(((w0*P0 + w1*P1 + add) >> sh) + post), P the 14-bit
+// intermediates (offset by -8192) of the lists in use.
+//   default, one list:  clip((P + 8192 + rnd) >> (14 - bd))                       (TComInterpolationFilter, isLast)
+//   default, two lists: TComYuv::addAvg (TLibCommon/TComYuv.cpp:520-584)
+//   explicit weights:   TComWeightPrediction::addWeightUni / addWeightBi with the parameters of getWpScaling
+//                       (TLibCommon/TComWeightPrediction.cpp:43-59,79-257,271-334)
+struct PredRound {
+  int w[2], add, sh, post;
+};
+__device__ __forceinline__ PredRound pred_round(const WpTables *wp, int r0, int r1, int comp, int bd) {
+  const int head = 14 - bd;
+  const bool bi = r0 >= 0 && r1 >= 0;
+  PredRound R;
+  if (!wp) {
+    R.w[0] = R.w[1] = 1;
+    R.sh = bi ? head + 1 : head;
+    R.add = bi ? 16384 + (1 << head) : 8192 + (head ? 1 << (head - 1) : 0);
+    R.post = 0;
+  } else if (bi) {
+    R.w[0] = wp->w[0][r0][comp];
+    R.w[1] = wp->w[1][r1][comp];
+    R.sh = wp->log2d[0][r0][comp] + 1 + head;
+    const int off = (wp->o[0][r0][comp] + wp->o[1][r1][comp]) * (1 << (bd - 8));
+    R.add = (R.w[0] + R.w[1]) * 8192 + (1 << (R.sh - 1)) + off * (1 << (R.sh - 1));
+    R.post = 0;
+  } else {
+    const int l = r0 >= 0 ? 0 : 1, r = l ? r1 : r0;
+    const int w = wp->w[l][r][comp];
+    R.w[l] = w;
+    R.w[l ^ 1] = 0;
+    R.sh = wp->log2d[l][r][comp] + head;
+    R.add = w * 8192 + (R.sh ? 1 << (R.sh - 1) : 0);
+    R.post = wp->o[l][r][comp] * (1 << (bd - 8));
+  }
+  return R;
+}
+
 // Motion-compensated prediction of one 4x4 luma unit (and its 2x2 chroma units) straight from its motion record.
-template <typename pel_t>
+// WP: the batch holds pictures with explicit weighted prediction (J.wp set for those).
+template <typename pel_t, bool WP>
 __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, int ux, int uy) {
   const Part4 p = J.rec4[(size_t)uy * s.uw + ux];
   if (p.flags & P4_INTRA) return;
@@ -300,11 +338,14 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
   const int hmax = (s.w + 8 - cux - 1) << 2, hmin = (-64 - 8 - cux + 1) << 2;
   const int vmax = (s.h + 8 - cuy - 1) << 2, vmin = (-64 - 8 - cuy + 1) << 2;
   bool use0 = p.ref_idx[0] >= 0, use1 = p.ref_idx[1] >= 0;
-  // TComPrediction::xCheckIdenticalMotion (TLibCommon/TComPrediction.cpp:396-411)
-  if (use0 && use1 && J.slice_type == 0 && J.ref_poc[0][p.ref_idx[0]] == J.ref_poc[1][p.ref_idx[1]] && p.mv[0][0] == p.mv[1][0] &&
+  // TComPrediction::xCheckIdenticalMotion (TLibCommon/TComPrediction.cpp:396-411); not with weighted bi-prediction
+  const WpTables *wp = WP ? J.wp : nullptr;
+  if (use0 && use1 && J.slice_type == 0 && !wp && J.ref_poc[0][p.ref_idx[0]] == J.ref_poc[1][p.ref_idx[1]] && p.mv[0][0] == p.mv[1][0] &&
       p.mv[0][1] == p.mv[1][1])
     use1 = false;
-  const bool bi = use0 && use1;
+  const int r0 = use0 ? p.ref_idx[0] : -1, r1 = use1 ? p.ref_idx[1] : -1;
+  const PredRound Ry = pred_round(wp, r0, r1, 0, s.bd_y);
+  const PredRound Rc[2] = {pred_round(wp, r0, r1, 1, s.bd_c), pred_round(wp, r0, r1, 2, s.bd_c)};
   int ly[4][4], lc[2][2][2];
 #pragma unroll
   for (int j = 0; j < 4; j++)
@@ -345,7 +386,7 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-          for (int i = 0; i < 4; i++) ly[j][i] += o[j][i];
+          for (int i = 0; i < 4; i++) ly[j][i] += WP ? __mul24(Ry.w[l], o[j][i]) : o[j][i];
       }
       {
         int tx[4], ty[4];
@@ -358,7 +399,7 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
 #pragma unroll
           for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int i = 0; i < 2; i++) lc[c][j][i] += o[j][i];
+            for (int i = 0; i < 2; i++) lc[c][j][i] += WP ? __mul24(Rc[c].w[l], o[j][i]) : o[j][i];
         }
       }
     }
@@ -376,7 +417,7 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-          for (int i = 0; i < 4; i++) ly[j][i] += o[j][i];
+          for (int i = 0; i < 4; i++) ly[j][i] += WP ? __mul24(Ry.w[l], o[j][i]) : o[j][i];
       }
       {
         int tx[4], ty[4];
@@ -390,21 +431,20 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
 #pragma unroll
           for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int i = 0; i < 2; i++) lc[c][j][i] += o[j][i];
+            for (int i = 0; i < 2; i++) lc[c][j][i] += WP ? __mul24(Rc[c].w[l], o[j][i]) : o[j][i];
         }
       }
     }
   }
-  // uni: clip((v + 8192 + rnd) >> (14 - bd)); bi: TComYuv::addAvg (TLibCommon/TComYuv.cpp:520-584)
   {
-    const int head = 14 - s.bd_y, maxv = (1 << s.bd_y) - 1;
-    const int sh = bi ? head + 1 : head, off = bi ? 16384 + (1 << head) : 8192 + (head ? (1 << (head - 1)) : 0);
+    const int maxv = (1 << s.bd_y) - 1;
+    const int sh = Ry.sh, off = Ry.add, post = Ry.post;
     pel_t *dst = (pel_t *)J.rec[0] + (size_t)y * s.stride_y + x;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       int v[4];
 #pragma unroll
-      for (int i = 0; i < 4; i++) v[i] = clip3i(0, maxv, (ly[j][i] + off) >> sh);
+      for (int i = 0; i < 4; i++) v[i] = clip3i(0, maxv, ((ly[j][i] + off) >> sh) + post);
       if constexpr (sizeof(pel_t) == 1) {
         *(unsigned *)dst = pack4(v[0], v[1], v[2], v[3]);  // x is a multiple of 4 and rows are 128-byte aligned
       } else {
@@ -415,15 +455,15 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
     }
   }
   {
-    const int head = 14 - s.bd_c, maxv = (1 << s.bd_c) - 1;
-    const int sh = bi ? head + 1 : head, off = bi ? 16384 + (1 << head) : 8192 + (head ? (1 << (head - 1)) : 0);
+    const int maxv = (1 << s.bd_c) - 1;
 #pragma unroll
     for (int c = 0; c < 2; c++) {
+      const int sh = Rc[c].sh, off = Rc[c].add, post = Rc[c].post;
       pel_t *dst = (pel_t *)J.rec[1 + c] + (size_t)(y >> 1) * s.stride_c + (x >> 1);
 #pragma unroll
       for (int j = 0; j < 2; j++) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) dst[i] = (pel_t)clip3i(0, maxv, (lc[c][j][i] + off) >> sh);
+        for (int i = 0; i < 2; i++) dst[i] = (pel_t)clip3i(0, maxv, ((lc[c][j][i] + off) >> sh) + post);
         dst += s.stride_c;
       }
     }
@@ -431,7 +471,7 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
 }
 
 // k_inter_blk: 16x16 regions with mixed motion.  One wave per four regions, one lane per 4x4 unit.
-template <typename pel_t>
+template <typename pel_t, bool WP>
 __global__ __launch_bounds__(256) void k_inter_blk(const PicJob *jobs, SeqInfo s) {
   const PicJob &J = jobs[blockIdx.y];
   const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -440,7 +480,7 @@ __global__ __launch_bounds__(256) void k_inter_blk(const PicJob *jobs, SeqInfo s
   const int u = threadIdx.x & 15;
   const int ux = (b.x >> 2) + (u & 3), uy = (b.y >> 2) + (u >> 2);
   if (ux >= s.uw || uy >= s.uh) return;
-  inter_unit<pel_t>(J, s, ux, uy);
+  inter_unit<pel_t, WP>(J, s, ux, uy);
 }
 
 // ---- k_inter_tile: regions with uniform motion -----------------------------------------------------------
@@ -469,8 +509,8 @@ __device__ __forceinline__ int hr_sdot2(unsigned a, unsigned b, int c) {
 // optimiser on purpose: hipcc (ROCm 7.2) otherwise fuses "shift, clamp to 0..255, pack two bytes" into
 // v_ashr_pk_u8_i32 and then ORs the other two bytes into the upper half of its result register, which that
 // instruction does not clear on gfx950 (the upper bytes of a negative input came out as 0xFF).
-__device__ __forceinline__ int tile_px(int v, int off, int sh, int maxv = 255) {
-  int x = (v + off) >> sh;
+__device__ __forceinline__ int tile_px(int v, int off, int sh, int maxv = 255, int post = 0) {
+  int x = ((v + off) >> sh) + post;
 #ifndef HEVCRECON_EMULATE
   asm volatile("" : "+v"(x));
 #endif
@@ -545,7 +585,7 @@ __constant__ unsigned kChromaTab[8][8] = {HR_C4(0, 64, 0, 0),    HR_C4(-2, 58, 1
 __device__ __forceinline__ int hr_sdot4z(unsigned a, unsigned b) { return hr_sdot4(a, b, 0); }
 __device__ __forceinline__ int hr_sdot2z(unsigned a, unsigned b) { return hr_sdot2(a, b, 0); }
 
-template <typename pel_t, int TS, int NTHR>
+template <typename pel_t, int TS, int NTHR, bool WP>
 __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_tile(const PicJob *jobs, SeqInfo s) {
   constexpr bool W16 = sizeof(pel_t) == 2;  // 16-bit planes: 16-bit dot products in the horizontal pass too
   constexpr int WD = W16 ? 8 : 4;           // dwords fetched per window row and work item (16 samples)
@@ -568,7 +608,6 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
   const McTile t = J.mc_tile[LVL][idx];
   const int tid = threadIdx.x;
   const int rx = t.x, ry = t.y;
-  const int nl = (t.ref[0] >= 0 ? 1 : 0) + (t.ref[1] >= 0 ? 1 : 0);
   // a list with a zero vertical fraction needs no vertical filter: its rows outside the block are never read
   const bool vid_y[2] = {(t.mv[0][1] & 3) == 0, (t.mv[1][1] & 3) == 0};
   const bool vid_c[2] = {(t.mv[0][1] & 7) == 0, (t.mv[1][1] & 7) == 0};
@@ -673,11 +712,11 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
   __syncthreads();
 
   // ---- phase V: one lane per two rows x four columns, result stored as one dword per row ----
-  const bool bi = nl == 2;
-  // uni: clip((v + 8192 + rnd) >> (14 - bd)); bi: TComYuv::addAvg, (v0 + v1 + 16384 + (1 << (14 - bd))) >> (15 - bd)
-  const int head_y = 14 - s.bd_y, head_c = 14 - s.bd_c;
-  const int fsh_y = bi ? head_y + 1 : head_y, foff_y = bi ? 16384 + (1 << head_y) : 8192 + (head_y ? 1 << (head_y - 1) : 0);
-  const int fsh_c = bi ? head_c + 1 : head_c, foff_c = bi ? 16384 + (1 << head_c) : 8192 + (head_c ? 1 << (head_c - 1) : 0);
+  // final rounding per component (default: one list clip((v + 8192 + rnd) >> (14 - bd)), two lists TComYuv::addAvg;
+  // explicit weights when the picture carries them)
+  const WpTables *wp = WP ? J.wp : nullptr;
+  const PredRound Ry = pred_round(wp, t.ref[0], t.ref[1], 0, s.bd_y);
+  const PredRound Rcb = pred_round(wp, t.ref[0], t.ref[1], 1, s.bd_c), Rcr = pred_round(wp, t.ref[0], t.ref[1], 2, s.bd_c);
   const int max_y = (1 << s.bd_y) - 1, max_c = (1 << s.bd_c) - 1;
   constexpr int LT = TS * TS / 8, CT = 2 * CS * CS / 8;  // luma and chroma work items
   for (int v0 = 0; v0 < LT + CT; v0 += NTHR) {
@@ -696,8 +735,9 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
           const unsigned qa[4] = {a.x, a.y, a.z, a.w}, qb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
           for (int c = 0; c < 4; c++) {
-            acc[0][c] += (int)qa[c] >> 16;
-            acc[1][c] += (int)(int16_t)(qb[c] & 0xffff);
+            const int a0 = (int)qa[c] >> 16, a1 = (int)(int16_t)(qb[c] & 0xffff);
+            acc[0][c] += WP ? __mul24(Ry.w[l], a0) : a0;
+            acc[1][c] += WP ? __mul24(Ry.w[l], a1) : a1;
           }
         } else {
           const unsigned *lt = kLumaTab[t.mv[l][1] & 3];
@@ -710,9 +750,11 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
           }
 #pragma unroll
           for (int c = 0; c < 4; c++) {
-            acc[0][c] += hr_sdot2(qq[3][c], e3, hr_sdot2(qq[2][c], e2, hr_sdot2(qq[1][c], e1, hr_sdot2z(qq[0][c], e0)))) >> 6;
-            acc[1][c] +=
+            const int a0 = hr_sdot2(qq[3][c], e3, hr_sdot2(qq[2][c], e2, hr_sdot2(qq[1][c], e1, hr_sdot2z(qq[0][c], e0)))) >> 6;
+            const int a1 =
                 hr_sdot2(qq[4][c], o4, hr_sdot2(qq[3][c], o3, hr_sdot2(qq[2][c], o2, hr_sdot2(qq[1][c], o1, hr_sdot2z(qq[0][c], o0))))) >> 6;
+            acc[0][c] += WP ? __mul24(Ry.w[l], a0) : a0;
+            acc[1][c] += WP ? __mul24(Ry.w[l], a1) : a1;
           }
         }
       }
@@ -723,7 +765,7 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
           if (y < s.h) {
             int px[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) px[c] = tile_px(acc[j][c], foff_y, fsh_y, max_y);
+            for (int c = 0; c < 4; c++) px[c] = tile_px(acc[j][c], Ry.add, Ry.sh, max_y, WP ? Ry.post : 0);
             pel_t *o = (pel_t *)J.rec[0] + (size_t)y * s.stride_y + rx + 4 * q;
             if constexpr (W16)
               *(uint2 *)o = make_uint2(pack16(px[0], px[1]), pack16(px[2], px[3]));
@@ -737,6 +779,7 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
       const int comp = vc >= CT / 2 ? 1 : 0, r = vc - comp * (CT / 2);
       const int q = r % (CS / 4), rp = r / (CS / 4);
       int acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+      const PredRound &Rc = comp ? Rcr : Rcb;
 #pragma unroll
       for (int l = 0; l < 2; l++) {
         if (t.ref[l] < 0 || vc >= CT) continue;
@@ -746,8 +789,9 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
           const unsigned qa[4] = {a.x, a.y, a.z, a.w}, qb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
           for (int c = 0; c < 4; c++) {
-            acc[0][c] += (int)qa[c] >> 16;
-            acc[1][c] += (int)(int16_t)(qb[c] & 0xffff);
+            const int a0 = (int)qa[c] >> 16, a1 = (int)(int16_t)(qb[c] & 0xffff);
+            acc[0][c] += WP ? __mul24(Rc.w[l], a0) : a0;
+            acc[1][c] += WP ? __mul24(Rc.w[l], a1) : a1;
           }
         } else {
           const unsigned *ct = kChromaTab[t.mv[l][1] & 7];
@@ -760,8 +804,10 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
           }
 #pragma unroll
           for (int c = 0; c < 4; c++) {
-            acc[0][c] += hr_sdot2(qq[1][c], e1, hr_sdot2z(qq[0][c], e0)) >> 6;
-            acc[1][c] += hr_sdot2(qq[2][c], o2, hr_sdot2(qq[1][c], o1, hr_sdot2z(qq[0][c], o0))) >> 6;
+            const int a0 = hr_sdot2(qq[1][c], e1, hr_sdot2z(qq[0][c], e0)) >> 6;
+            const int a1 = hr_sdot2(qq[2][c], o2, hr_sdot2(qq[1][c], o1, hr_sdot2z(qq[0][c], o0))) >> 6;
+            acc[0][c] += WP ? __mul24(Rc.w[l], a0) : a0;
+            acc[1][c] += WP ? __mul24(Rc.w[l], a1) : a1;
           }
         }
       }
@@ -773,7 +819,7 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
           if (y < s.ch) {
             int px[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) px[c] = tile_px(acc[j][c], foff_c, fsh_c, max_c);
+            for (int c = 0; c < 4; c++) px[c] = tile_px(acc[j][c], Rc.add, Rc.sh, max_c, WP ? Rc.post : 0);
             pel_t *o = (pel_t *)J.rec[1 + comp] + (size_t)y * s.stride_c + cx;
             if constexpr (W16)
               *(uint2 *)o = make_uint2(pack16(px[0], px[1]), pack16(px[2], px[3]));
@@ -1663,15 +1709,20 @@ template <typename pel_t>
 static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t st, int arg, int arg2) {
   switch (kind) {
     case K_INTER:
-      // arg = 0..2: uniform regions of 64 / 32 / 16 samples, 3: mixed regions; arg2 = their largest count over the
-      // batch.  Tile grid.x is a multiple of 8, so that blockIdx.x & 7 is the XCD for every picture of the batch.
+      // arg = 0..2: uniform regions of 64 / 32 / 16 samples, 3: mixed regions, +4: some picture of the batch uses
+      // explicit weighted prediction; arg2 = the largest count of such regions over the batch.  Tile grid.x is a
+      // multiple of 8, so that blockIdx.x & 7 is the XCD for every picture of the batch.
       {
         const dim3 g((arg2 + 7) / 8 * 8, n);
-        if (arg == 0) LAUNCH((k_inter_tile<pel_t, 64, 512>), g, dim3(512), st, jobs, s);
-        if (arg == 1) LAUNCH((k_inter_tile<pel_t, 32, 128>), g, dim3(128), st, jobs, s);
-        if (arg == 2) LAUNCH((k_inter_tile<pel_t, 16, 64>), g, dim3(64), st, jobs, s);
+        if (arg == 0) LAUNCH((k_inter_tile<pel_t, 64, 512, false>), g, dim3(512), st, jobs, s);
+        if (arg == 1) LAUNCH((k_inter_tile<pel_t, 32, 128, false>), g, dim3(128), st, jobs, s);
+        if (arg == 2) LAUNCH((k_inter_tile<pel_t, 16, 64, false>), g, dim3(64), st, jobs, s);
+        if (arg == 4) LAUNCH((k_inter_tile<pel_t, 64, 512, true>), g, dim3(512), st, jobs, s);
+        if (arg == 5) LAUNCH((k_inter_tile<pel_t, 32, 128, true>), g, dim3(128), st, jobs, s);
+        if (arg == 6) LAUNCH((k_inter_tile<pel_t, 16, 64, true>), g, dim3(64), st, jobs, s);
       }
-      if (arg == 3) LAUNCH(k_inter_blk<pel_t>, dim3((arg2 + 15) / 16, n), dim3(256), st, jobs, s);
+      if (arg == 3) LAUNCH((k_inter_blk<pel_t, false>), dim3((arg2 + 15) / 16, n), dim3(256), st, jobs, s);
+      if (arg == 7) LAUNCH((k_inter_blk<pel_t, true>), dim3((arg2 + 15) / 16, n), dim3(256), st, jobs, s);
       break;
     case K_TRANSFORM: {
       // arg = log2 size, arg2 = max number of blocks of that size over the batch

@@ -54,6 +54,7 @@ void PackedPicture::begin(const SeqInfo &s) {
   lvl_y.assign((size_t)s.uw * s.uh, 0);
   lvl_c.assign((size_t)s.uw * s.uh, 0);
   use_scaling = false;
+  use_wp = false;
   has_bypass = false;
   has_pcm = false;
   mc_ref_samples = 0;
@@ -363,7 +364,8 @@ bool PackedPicture::finish(const hevcrecon_pic_params *p) {
 // 4x4 unit of it inside the picture is inter and resolves to the same prediction: same references, same
 // vectors after TComDataCU::clipMv (TLibCommon/TComDataCU.cpp:3207-3219, the range depends on the unit's
 // coding-unit origin), same outcome of TComPrediction::xCheckIdenticalMotion
-// (TLibCommon/TComPrediction.cpp:396-411).  Every CTU is tried whole, then by 32x32 quadrants, then by 16x16
+// (TLibCommon/TComPrediction.cpp:396-411; never taken with weighted bi-prediction).  Explicit weights depend on
+// the reference indices only, so they are uniform too.  Every CTU is tried whole, then by 32x32 quadrants, then by 16x16
 // blocks; what is left goes to mc_blk (16x16 granularity, predicted unit by unit).
 namespace {
 enum { MC_NONE, MC_UNIFORM, MC_MIXED };
@@ -388,7 +390,7 @@ int PackedPicture::classify_mc(int x0, int y0, int size, McTile *out) const {
       const int hmax = (seq.w + 8 - cux - 1) * 4, hmin = (-64 - 8 - cux + 1) * 4;
       const int vmax = (seq.h + 8 - cuy - 1) * 4, vmin = (-64 - 8 - cuy + 1) * 4;
       bool use[2] = {p.ref_idx[0] >= 0, p.ref_idx[1] >= 0};
-      if (use[0] && use[1] && pp.slice_type == 0 && p.ref_idx[0] < HR_MAX_REFS && p.ref_idx[1] < HR_MAX_REFS &&
+      if (use[0] && use[1] && pp.slice_type == 0 && !use_wp && p.ref_idx[0] < HR_MAX_REFS && p.ref_idx[1] < HR_MAX_REFS &&
           pp.ref_poc[0][p.ref_idx[0]] == pp.ref_poc[1][p.ref_idx[1]] && p.mv[0][0] == p.mv[1][0] && p.mv[0][1] == p.mv[1][1])
         use[1] = false;
       if (!use[0] && !use[1]) {

@@ -26,6 +26,8 @@ struct PackedPicture {
   bool has_pcm;                     // some coding unit is IPCM
   bool use_scaling;                 // the picture de-quantises with `scaling`
   ScalingTables scaling;
+  bool use_wp;                      // the picture predicts with the explicit weights `wp`
+  WpTables wp;
   int max_ref_idx[2];               // largest reference index used by an inter block, per list (-1: none)
   bool inter_without_ref;           // an inter block with no reference at all (corrupt input)
   int64_t mc_ref_samples;           // luma+chroma samples predicted, counted once per reference used

@@ -30,6 +30,8 @@ class Syntax:
         self.engine._check(lib.hevcrecon_syntax_begin(self.h), "hevcrecon_syntax_begin")
         if getattr(pic, "scaling", None) is not None:
             self.engine._check(lib.hevcrecon_syntax_set_scaling_lists(self.h, C.addressof(pic.scaling)), "hevcrecon_syntax_set_scaling_lists")
+        if getattr(pic, "pred_weights", None) is not None:
+            self.engine._check(lib.hevcrecon_syntax_set_pred_weights(self.h, C.addressof(pic.pred_weights)), "hevcrecon_syntax_set_pred_weights")
         ctus = pic.ctu_structs()
         for a in range(pic.nctu):
             self.engine._check(lib.hevcrecon_syntax_add_ctu(self.h, a, C.byref(ctus[a])), "hevcrecon_syntax_add_ctu")

@@ -22,6 +22,7 @@ from . import abi
 MAGIC = b"HVSYN1\0\0"
 PICT = 0x54434950
 SCAL = 0x4C414353  # optional record before a picture: the scaling lists it de-quantises with
+WPRD = 0x44525057  # optional record before a picture: its explicit prediction weights
 PCMS = 0x534D4350  # optional record before a picture: PCM sample arrays of the CTUs that hold IPCM units
 _PCM_CTU_BYTES = 4 + (16 + 4 + 4) * abi.PARTS_PER_CTU * 2
 P = abi.PARTS_PER_CTU
@@ -54,6 +55,7 @@ class PictureSyntax:
         self.a = {}          # name -> array
         self.sao = None      # (nctu, 3, 6) int32: type, subtype, offset[4]
         self.scaling = None  # abi.ScalingLists when the picture uses scaling lists
+        self.pred_weights = None  # abi.PredWeights when the picture predicts with explicit weights
         self.pcm = {}        # ctu address -> (y, cb, cr) int16 arrays, for the CTUs that hold IPCM units
         self.stage_md5 = None  # (3, 3) hex strings: [stage][component]
         self.planes = None   # optional [stage][component] 2-D uint16
@@ -138,10 +140,13 @@ def read_dump(path, max_pictures=None):
             tag, nctu, pic_id, has_planes = struct.unpack("<4i", hdr)
             scaling = None
             pcm = {}
-            while tag in (SCAL, PCMS):
+            weights = None
+            while tag in (SCAL, PCMS, WPRD):
                 if tag == SCAL:
                     # the 16 bytes just read are the record's tag + 12 bytes of padding
                     scaling = abi.ScalingLists.from_buffer_copy(f.read(C.sizeof(abi.ScalingLists)))
+                elif tag == WPRD:
+                    weights = abi.PredWeights.from_buffer_copy(f.read(C.sizeof(abi.PredWeights)))
                 else:
                     for _ in range(nctu):  # second header word: number of CTUs in the record
                         addr = struct.unpack("<i", f.read(4))[0]
@@ -154,6 +159,7 @@ def read_dump(path, max_pictures=None):
             pic.nctu, pic.pic_id = nctu, pic_id
             pic.scaling = scaling
             pic.pcm = pcm
+            pic.pred_weights = weights
             raw = f.read(C.sizeof(abi.PicParams))
             C.memmove(C.addressof(pic.pic_params), raw, len(raw))
 
@@ -203,6 +209,10 @@ def strip_planes_and_compress(src, dst, preset=6):
             if tag == SCAL:  # optional scaling-list record: copied as it is
                 out.write(hdr)
                 out.write(f.read(C.sizeof(abi.ScalingLists)))
+                continue
+            if tag == WPRD:
+                out.write(hdr)
+                out.write(f.read(C.sizeof(abi.PredWeights)))
                 continue
             if tag == PCMS:
                 out.write(hdr)

@@ -121,6 +121,17 @@ typedef struct hevcrecon_scaling_lists {
   uint8_t dc32[2];
 } hevcrecon_scaling_lists;
 
+/* Explicit weighted prediction of a picture's slice: the entries of TComSlice::m_weightPredTable
+ * (wpScalingParam: uiLog2WeightDenom, iWeight, iOffset; TLibCommon/TComSlice.h:1104-1118, read through
+ * TComSlice::getWpScaling by TComWeightPrediction::getWpScaling, TLibCommon/TComWeightPrediction.cpp:271-334),
+ * indexed [list][reference index][component Y, Cb, Cr].  Entries without a transmitted weight hold the parser's
+ * defaults (weight 1 << denominator, offset 0).  Offsets are the transmitted 8-bit-scale values. */
+typedef struct hevcrecon_pred_weights {
+  int16_t log2_denom[2][HEVCRECON_MAX_REFS][3];
+  int16_t weight[2][HEVCRECON_MAX_REFS][3];
+  int16_t offset[2][HEVCRECON_MAX_REFS][3];
+} hevcrecon_pred_weights;
+
 /* ---- context ---------------------------------------------------------- */
 
 /* Creates an engine on HIP device `device`.  Fails (non-zero, *out = NULL) when no GPU is present. */
@@ -162,6 +173,14 @@ int hevcrecon_syntax_begin(hevcrecon_syntax *syn);
  * the flat path.  Replaces m_cTrQuant.setScalingListDec / setUseScalingList(true) (TLibDecoder/TDecTop.cpp:560-561).
  * NULL returns to flat de-quantisation.  hevcrecon_syntax_begin resets to flat. */
 int hevcrecon_syntax_set_scaling_lists(hevcrecon_syntax *syn, const hevcrecon_scaling_lists *lists);
+
+/* Optional, between hevcrecon_syntax_begin and hevcrecon_syntax_finish: the picture's inter prediction uses explicit
+ * weights (TComWeightPrediction::xWeightedPredictionUni / xWeightedPredictionBi instead of the plain rounding /
+ * TComYuv::addAvg; TLibCommon/TComPrediction.cpp:519-542).  The caller passes them exactly when the reference would
+ * weight: P slice with pps->getUseWP(), or B slice with pps->getWPBiPred(); the identical-motion shortcut
+ * (TComPrediction::xCheckIdenticalMotion, :396-411) is then off for B slices, as in the reference.
+ * NULL returns to default prediction.  hevcrecon_syntax_begin resets to default. */
+int hevcrecon_syntax_set_pred_weights(hevcrecon_syntax *syn, const hevcrecon_pred_weights *weights);
 
 /* Replaces the call m_pcCuDecoder->decompressCU(pcCU) in TDecSlice::decompressSlice
  * (TLibDecoder/TDecSlice.cpp:367): instead of reconstructing the CTU at once, its syntax

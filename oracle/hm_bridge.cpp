@@ -61,6 +61,7 @@ struct EngineApi {
   int (*syntax_create)(hevcrecon_ctx *, hevcrecon_syntax **);
   int (*syntax_begin)(hevcrecon_syntax *);
   int (*syntax_set_scaling_lists)(hevcrecon_syntax *, const hevcrecon_scaling_lists *);
+  int (*syntax_set_pred_weights)(hevcrecon_syntax *, const hevcrecon_pred_weights *);
   int (*syntax_add_ctu)(hevcrecon_syntax *, int, const hevcrecon_ctu_syntax *);
   int (*syntax_finish)(hevcrecon_syntax *, const hevcrecon_pic_params *);
   int (*reconstruct)(hevcrecon_ctx *, hevcrecon_syntax *, int);
@@ -111,6 +112,7 @@ struct Bridge {
     sym(api.syntax_create, "hevcrecon_syntax_create");
     sym(api.syntax_begin, "hevcrecon_syntax_begin");
     sym(api.syntax_set_scaling_lists, "hevcrecon_syntax_set_scaling_lists");
+    sym(api.syntax_set_pred_weights, "hevcrecon_syntax_set_pred_weights");
     sym(api.syntax_add_ctu, "hevcrecon_syntax_add_ctu");
     sym(api.syntax_finish, "hevcrecon_syntax_finish");
     sym(api.reconstruct, "hevcrecon_reconstruct");
@@ -184,6 +186,26 @@ struct Bridge {
       for (int i = 0; i < 64; i++) sl.m32[id][i] = (uint8_t)l->getScalingListAddress(SCALING_LIST_32x32, id)[i];
       sl.dc32[id] = (uint8_t)l->getScalingListDC(SCALING_LIST_32x32, id);
     }
+    return true;
+  }
+
+  // The slice's explicit prediction weights, when the reference would use them (TLibCommon/TComPrediction.cpp:519-538).
+  bool fill_weights(TComPic *pic, hevcrecon_pred_weights &pw) {
+    TComSlice *s = pic->getSlice(pic->getCurrSliceIdx());
+    const bool weighted = (s->getSliceType() == P_SLICE && s->getPPS()->getUseWP()) ||
+                          (s->getSliceType() == B_SLICE && s->getPPS()->getWPBiPred());
+    if (!weighted) return false;
+    memset(&pw, 0, sizeof(pw));
+    for (int l = 0; l < 2; l++)
+      for (int r = 0; r < s->getNumRefIdx(RefPicList(l)) && r < HEVCRECON_MAX_REFS; r++) {
+        wpScalingParam *wp;
+        s->getWpScaling(RefPicList(l), r, wp);
+        for (int c = 0; c < 3; c++) {
+          pw.log2_denom[l][r][c] = (int16_t)wp[c].uiLog2WeightDenom;
+          pw.weight[l][r][c] = (int16_t)wp[c].iWeight;
+          pw.offset[l][r][c] = (int16_t)wp[c].iOffset;
+        }
+      }
     return true;
   }
 
@@ -297,6 +319,12 @@ struct Bridge {
         }
       }
     }
+    hevcrecon_pred_weights pw;
+    if (fill_weights(pic, pw)) {  // optional record in front of the picture
+      int32_t whdr[4] = {0x44525057 /* "WPRD" */, 0, 0, 0};
+      put(whdr, 4);
+      put(&pw, 1);
+    }
     int32_t hdr[4] = {0x54434950 /* "PICT" */, nctu, pic_id(pic), dump_planes ? 1 : 0};
     put(hdr, 4);
     put(&pp, 1);
@@ -350,6 +378,8 @@ struct Bridge {
     if (api.syntax_begin(syn)) fail("hevcrecon_syntax_begin");
     hevcrecon_scaling_lists sl;
     if (fill_scaling(pic, sl) && api.syntax_set_scaling_lists(syn, &sl)) fail("hevcrecon_syntax_set_scaling_lists");
+    hevcrecon_pred_weights pw;
+    if (fill_weights(pic, pw) && api.syntax_set_pred_weights(syn, &pw)) fail("hevcrecon_syntax_set_pred_weights");
     int nctu = pic->getNumCUsInFrame();
     for (int a = 0; a < nctu; a++) {
       hevcrecon_ctu_syntax cs;

@@ -38,6 +38,8 @@ typedef struct hevcref_ctx {
   const hevcrecon_ctu_syntax *ctus;
   int use_sl;                 /* de-quantise with the scaling lists below */
   hevcrecon_scaling_lists sl;
+  int use_wp;                 /* predict with the explicit weights below */
+  hevcrecon_pred_weights wp;
   int16_t *rec[3];
   uint8_t zscan_x[NPART], zscan_y[NPART]; /* partition z index -> x,y in 4-sample units */
   uint8_t raster_to_z[16][16];             /* [y][x] -> z */
@@ -333,7 +335,8 @@ static void predict_pu(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, in
     mv[l][1] = imin(vmax, imax(vmin, ctu->mv[l][2 * z + 1]));
   }
   int use[2] = {r0 >= 0, r1 >= 0};
-  if (use[0] && use[1] && c->pp->slice_type == 0 && c->pp->ref_poc[0][r0] == c->pp->ref_poc[1][r1] &&
+  /* TComPrediction::xCheckIdenticalMotion, TLibCommon/TComPrediction.cpp:396-411 (B slices without weighted bi-prediction) */
+  if (use[0] && use[1] && c->pp->slice_type == 0 && !c->use_wp && c->pp->ref_poc[0][r0] == c->pp->ref_poc[1][r1] &&
       ctu->mv[0][2 * z] == ctu->mv[1][2 * z] && ctu->mv[0][2 * z + 1] == ctu->mv[1][2 * z + 1])
     use[1] = 0; /* identical motion: plain uni-prediction from list 0 */
   int bi = use[0] && use[1];
@@ -343,6 +346,36 @@ static void predict_pu(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, in
     int bw = pw >> sh, bh = ph >> sh, stride = 64 >> sh;
     int16_t *dst = pred[comp] + ((py - cuy) >> sh) * stride + ((px - cux) >> sh);
     int bd = bit_depth(c, comp);
+    if (c->use_wp) {
+      /* TComPrediction::xPredInterBi with weights, TLibCommon/TComPrediction.cpp:513-538: every list in use is
+       * predicted to the 14-bit intermediate, then TComWeightPrediction::xWeightedPredictionUni / -Bi
+       * (TLibCommon/TComWeightPrediction.cpp:43-59,79-257) with the parameters of getWpScaling (:271-334) */
+      const hevcrecon_pred_weights *wp = &c->wp;
+      int maxv = (1 << bd) - 1, shift_num = 14 - bd;
+      for (int l = 0; l < 2; l++) {
+        if (!use[l]) continue;
+        const Pic *rp = &c->pics[c->pp->ref_pic_id[l][l ? r1 : r0]];
+        mc_block(c, rp->p[comp], comp, px >> sh, py >> sh, bw, bh, mv[l][0], mv[l][1], 1, l ? t1 : t0, bw);
+      }
+      if (bi) {
+        int w0 = wp->weight[0][r0][comp], w1 = wp->weight[1][r1][comp];
+        int offset = wp->offset[0][r0][comp] * (1 << (bd - 8)) + wp->offset[1][r1][comp] * (1 << (bd - 8));
+        int shift = wp->log2_denom[0][r0][comp] + 1 + shift_num, round = 1 << (shift - 1);
+        for (int y = 0; y < bh; y++)
+          for (int x = 0; x < bw; x++)
+            dst[y * stride + x] = (int16_t)clip3(
+                0, maxv, (w0 * (t0[y * bw + x] + 8192) + w1 * (t1[y * bw + x] + 8192) + round + offset * (1 << (shift - 1))) >> shift);
+      } else {
+        int l = use[0] ? 0 : 1, ri = l ? r1 : r0;
+        const int16_t *t = l ? t1 : t0;
+        int w = wp->weight[l][ri][comp], offset = wp->offset[l][ri][comp] * (1 << (bd - 8));
+        int shift = wp->log2_denom[l][ri][comp] + shift_num, round = shift ? 1 << (shift - 1) : 0;
+        for (int y = 0; y < bh; y++)
+          for (int x = 0; x < bw; x++)
+            dst[y * stride + x] = (int16_t)clip3(0, maxv, ((w * (t[y * bw + x] + 8192) + round) >> shift) + offset);
+      }
+      continue;
+    }
     for (int l = 0; l < 2; l++) {
       if (!use[l]) continue;
       int ri = l ? r1 : r0;
@@ -917,6 +950,12 @@ static void sao_ctu(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int c
 void hevcref_set_scaling_lists(hevcref_ctx *c, const hevcrecon_scaling_lists *sl) {
   c->use_sl = sl != NULL;
   if (sl) c->sl = *sl;
+}
+
+/* Explicit prediction weights for the pictures reconstructed from now on (NULL: default prediction). */
+void hevcref_set_pred_weights(hevcref_ctx *c, const hevcrecon_pred_weights *w) {
+  c->use_wp = w != NULL;
+  if (w) c->wp = *w;
 }
 
 int hevcref_reconstruct(hevcref_ctx *c, const hevcrecon_pic_params *pp, const hevcrecon_ctu_syntax *ctus, int nctu, int dst_id) {

@@ -94,3 +94,35 @@ def test_scaling_lists_are_what_makes_the_scalinglist_stream_match():
     ref.reconstruct(pic)
     luma = ref.download(2, pic.pic_id)[0]
     assert syntax.plane_md5(luma, seq.seq_params.bit_depth_luma) != pic.stage_md5[2][0]
+
+
+@pytest.mark.parametrize("stream", ["wpp", "wpb"])
+def test_weights_are_what_makes_the_weighted_streams_match(stream):
+    """Negative control for the weighted-prediction fixtures: predicted without the weights, the first inter picture
+    must NOT reproduce the reference's digest."""
+    import copy
+
+    seq = load_golden(stream + "_416x240", 2)
+    ref = RefModel(seq.seq_params)
+    ref.reconstruct(seq.pictures[0])
+    pic = copy.copy(seq.pictures[1])
+    assert pic.pred_weights is not None
+    pic.pred_weights = None
+    ref.reconstruct(pic)
+    luma = ref.download(2, pic.pic_id)[0]
+    assert syntax.plane_md5(luma, seq.seq_params.bit_depth_luma) != pic.stage_md5[2][0]
+
+
+def test_pcm_samples_are_what_makes_the_pcm_stream_match():
+    """Negative control for the IPCM fixture: with the PCM sample arrays zeroed its first picture must NOT match."""
+    import copy
+
+    seq = load_golden("pcm_416x240", 1)
+    pic = copy.copy(seq.pictures[0])
+    assert pic.pcm
+    pic.pcm = {a: tuple(p * 0 for p in planes) for a, planes in pic.pcm.items()}
+    pic._keep = None
+    ref = RefModel(seq.seq_params)
+    ref.reconstruct(pic)
+    luma = ref.download(2, pic.pic_id)[0]
+    assert syntax.plane_md5(luma, seq.seq_params.bit_depth_luma) != pic.stage_md5[2][0]

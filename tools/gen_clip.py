@@ -10,6 +10,8 @@ avoided on purpose: it would yield almost only integer motion vectors and the
 usage: gen_clip.py WIDTH HEIGHT FRAMES SEED OUT.yuv [noise]
 With "noise" a 104x88 patch of white noise (all three planes) is pasted at luma (36, 44) of every frame:
 incompressible content, for which an encoder with PCM enabled picks IPCM coding units at low QP.
+With "fade" the clip fades towards black (luma scaled by 1 - 0.08 t, chroma amplitude likewise), which makes an
+encoder with weighted prediction enabled pick non-trivial weights and offsets.
 """
 import sys
 import numpy as np
@@ -36,7 +38,7 @@ def _bilinear(tex, yy, xx):
             + fy * ((1 - fx) * tex[y1, x0] + fx * tex[y1, x1]))
 
 
-def frames(width, height, nframes, seed, noise=False):
+def frames(width, height, nframes, seed, noise=False, fade=False):
     rng = np.random.default_rng(seed)
     nrng = np.random.default_rng(seed + 1)
     tex = _box3(rng.integers(0, 256, (2 * height, 2 * width)).astype(np.float32))
@@ -55,6 +57,9 @@ def frames(width, height, nframes, seed, noise=False):
         luma[py:py + oh, px:px + ow] = _bilinear(tex, oy - 0.75 * t + 300, ox - 1.25 * t + 500)
         cb = 128 + 20 * np.sin((cx + 1.5 * t) / 17.0)
         cr = 128 + 30 * np.cos((cy + 0.75 * t) / 11.0)
+        if fade:
+            g = 1.0 - 0.08 * t
+            luma, cb, cr = luma * g + 6.0 * t, 128 + (cb - 128) * g, 128 + (cr - 128) * g
         planes = [np.clip(np.rint(p), 0, 255).astype(np.uint8) for p in (luma, cb, cr)]
         if noise:
             planes[0][44:132, 36:140] = nrng.integers(0, 256, (88, 104))
@@ -66,7 +71,7 @@ def frames(width, height, nframes, seed, noise=False):
 def main():
     w, h, n, seed = (int(a) for a in sys.argv[1:5])
     with open(sys.argv[5], "wb") as f:
-        for planes in frames(w, h, n, seed, noise=len(sys.argv) > 6 and sys.argv[6] == "noise"):
+        for planes in frames(w, h, n, seed, noise="noise" in sys.argv[6:], fade="fade" in sys.argv[6:]):
             for p in planes:
                 f.write(p.tobytes())
 
