@@ -48,7 +48,12 @@ class PicParams(C.Structure):
         ("num_ref", C.c_int32 * 2),
         ("ref_pic_id", (C.c_int32 * MAX_REFS) * 2),
         ("ref_poc", (C.c_int32 * MAX_REFS) * 2),
+        ("constrained_intra_pred", C.c_int32),
+        ("reserved", C.c_int32 * 7),
     ]
+
+# size of the structure in dumps of format 1 (before constrained_intra_pred + reserved were appended)
+PIC_PARAMS_SIZE_V1 = (13 + 2 * MAX_REFS * 2) * 4
 
 
 class CtuSyntax(C.Structure):

@@ -45,6 +45,7 @@ void PackedPicture::begin(const SeqInfo &s) {
   for (int i = 0; i < 4; i++) tu[i].clear();
   coeff.clear();
   intra.clear();
+  intra_nb.clear();
   ictu.clear();
   ictu_wave.clear();
   lvl_counts.clear();
@@ -83,6 +84,7 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
     for (int i = 0; i < 4; i++) s.offset[i] = (int8_t)ctu->sao_offset[c][i];
   }
   ctu_items.clear();
+  ctu_item_nb.clear();
   ctu_item_lvl.clear();
   ctu_dep_wave = 0;
   const int cx = addr % seq.ctus_w, cy = addr / seq.ctus_w;
@@ -103,7 +105,12 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
     for (int l = 1; l <= nlev; l++) lvl_counts.push_back((uint16_t)start[l + 1]);
     for (int l = 1; l <= nlev + 1; l++) start[l] += start[l - 1];
     intra.resize(ic.item_start + ctu_items.size());
-    for (size_t i = 0; i < ctu_items.size(); i++) intra[ic.item_start + start[ctu_item_lvl[i]]++] = ctu_items[i];
+    intra_nb.resize(intra.size());
+    for (size_t i = 0; i < ctu_items.size(); i++) {
+      const size_t at = ic.item_start + start[ctu_item_lvl[i]]++;
+      intra[at] = ctu_items[i];
+      intra_nb[at] = ctu_item_nb[i];
+    }
     // wave: after every neighbouring CTU whose intra blocks this CTU's blocks actually read (found while the
     // blocks' neighbour masks were built)
     const int wave = ctu_dep_wave;
@@ -247,12 +254,16 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
   const int cur = coding_order(ux0, uy0);
   // A neighbouring unit can be used iff it is inside the picture and precedes this block in coding order
   // (TComPattern::is*Available over TComDataCU::getPU*, TLibCommon/TComPattern.cpp:653-830,
-  // TLibCommon/TComDataCU.cpp:1141-1589, for one slice / one tile / unconstrained intra prediction).
+  // TLibCommon/TComDataCU.cpp:1141-1589, for one slice / one tile); with constrained intra prediction it must
+  // also be intra itself.
   // Local dependency level: one more than the highest level among the intra blocks OF THE SAME CTU that cover
   // an available neighbouring unit (blocks of other CTUs are finished before this CTU starts: CTU waves).
   const int my_cx = ux0 >> 4, my_cy = uy0 >> 4;
   // A unit of ANOTHER CTU matters only when an intra block covers it: then this CTU has to wait for that CTU's
   // wave (inter samples are final before any intra kernel runs).
+  auto usable = [&](int ux, int uy) -> bool { return coding_order(ux, uy) < cur; };
+  auto is_intra = [&](int ux, int uy) -> bool { return (rec4[(size_t)uy * seq.uw + ux].flags & P4_INTRA) != 0; };
+  IntraNeighbours nb = {0, 0, 0};
   auto level_at = [&](int ux, int uy) -> int {
     if ((ux >> 4) == my_cx && (uy >> 4) == my_cy) return lvl[(size_t)uy * seq.uw + ux];
     if (rec4[(size_t)uy * seq.uw + ux].flags & P4_INTRA)
@@ -264,20 +275,23 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
   int corner = 0;
   for (int j = 0; j < 2 * nu; j++) {
     const int ux = ux0 - 1, uy = uy0 + j;
-    if (ux >= 0 && uy < seq.uh && coding_order(ux, uy) < cur) {
+    if (ux >= 0 && uy < seq.uh && usable(ux, uy)) {
       left |= (uint16_t)(1u << j);
+      if (is_intra(ux, uy)) nb.left |= (uint16_t)(1u << j);
       level = std::max<int>(level, level_at(ux, uy));
     }
   }
   for (int i = 0; i < 2 * nu; i++) {
     const int ux = ux0 + i, uy = uy0 - 1;
-    if (uy >= 0 && ux < seq.uw && coding_order(ux, uy) < cur) {
+    if (uy >= 0 && ux < seq.uw && usable(ux, uy)) {
       above |= (uint16_t)(1u << i);
+      if (is_intra(ux, uy)) nb.above |= (uint16_t)(1u << i);
       level = std::max<int>(level, level_at(ux, uy));
     }
   }
-  if (ux0 > 0 && uy0 > 0) {
+  if (ux0 > 0 && uy0 > 0 && usable(ux0 - 1, uy0 - 1)) {
     corner = 1;
+    nb.corner = is_intra(ux0 - 1, uy0 - 1) ? 1 : 0;
     level = std::max<int>(level, level_at(ux0 - 1, uy0 - 1));
   }
   level += 1;
@@ -302,6 +316,7 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
     it.resi_off = off;
   }
   ctu_items.push_back(it);
+  ctu_item_nb.push_back(nb);
   ctu_item_lvl.push_back((uint16_t)level);
 }
 
@@ -338,6 +353,15 @@ bool PackedPicture::finish(const hevcrecon_pic_params *p) {
     if (pp.num_ref[l] < 0 || pp.num_ref[l] > HR_MAX_REFS) {
       error = "bad reference list size";
       return false;
+    }
+  // Constrained intra prediction (TComPattern::is*Available, TLibCommon/TComPattern.cpp:653-830): a neighbour counts
+  // only when it is intra itself.  Levels and waves were derived from the larger neighbour sets, which stays a valid
+  // (merely longer) order.
+  if (pp.constrained_intra_pred)
+    for (size_t i = 0; i < intra.size(); i++) {
+      intra[i].avail_left &= intra_nb[i].left;
+      intra[i].avail_above &= intra_nb[i].above;
+      if (!intra_nb[i].corner) intra[i].flags &= (uint8_t)~IN_CORNER;
     }
   // order the CTUs that hold intra blocks by wave
   int nw = 0;

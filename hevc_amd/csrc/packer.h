@@ -38,6 +38,14 @@ struct PackedPicture {
   // scratch
   std::vector<IntraItem> ctu_items;   // intra blocks of the CTU being added, in coding order
   std::vector<uint16_t> ctu_item_lvl; // their local levels
+  // Per intra block, which of its available neighbour units are themselves intra (same bit layout as
+  // IntraItem::avail_left / avail_above, bit 0 of `corner`): constrained intra prediction, known only when the
+  // picture parameters arrive, keeps just those.
+  struct IntraNeighbours {
+    uint16_t left, above;
+    uint8_t corner;
+  };
+  std::vector<IntraNeighbours> ctu_item_nb, intra_nb;  // of ctu_items / of intra (same indices)
   std::vector<uint16_t> lvl_y, lvl_c; // per 4x4 unit: local level of the intra block covering it (0 = none)
   std::vector<uint16_t> ctu_wave;     // per CTU: wave (0 = no intra blocks)
   std::vector<uint16_t> ictu_wave;    // parallel to ictu before sorting

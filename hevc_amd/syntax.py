@@ -19,7 +19,8 @@ import numpy as np
 
 from . import abi
 
-MAGIC = b"HVSYN1\0\0"
+MAGIC = b"HVSYN2\0\0"
+MAGIC_V1 = b"HVSYN1\0\0"  # older dumps: shorter picture parameters (abi.PIC_PARAMS_SIZE_V1)
 PICT = 0x54434950
 SCAL = 0x4C414353  # optional record before a picture: the scaling lists it de-quantises with
 WPRD = 0x44525057  # optional record before a picture: its explicit prediction weights
@@ -128,8 +129,10 @@ def read_dump(path, max_pictures=None):
     """Read a syntax dump written by the bridge decoder (raw or .xz)."""
     seq = Sequence()
     with _open(path) as f:
-        if f.read(8) != MAGIC:
+        magic = f.read(8)
+        if magic not in (MAGIC, MAGIC_V1):
             raise ValueError("%s: not a syntax dump" % path)
+        pp_size = C.sizeof(abi.PicParams) if magic == MAGIC else abi.PIC_PARAMS_SIZE_V1
         raw = f.read(C.sizeof(abi.SeqParams))
         C.memmove(C.addressof(seq.seq_params), raw, len(raw))
         w, h = seq.seq_params.width, seq.seq_params.height
@@ -160,7 +163,7 @@ def read_dump(path, max_pictures=None):
             pic.scaling = scaling
             pic.pcm = pcm
             pic.pred_weights = weights
-            raw = f.read(C.sizeof(abi.PicParams))
+            raw = f.read(pp_size)
             C.memmove(C.addressof(pic.pic_params), raw, len(raw))
 
             def arr(dtype, per_ctu):
@@ -197,6 +200,9 @@ def strip_planes_and_compress(src, dst, preset=6):
     """Re-write a raw dump without the stage pictures, xz-compressed (fixture maker)."""
     seq_size = C.sizeof(abi.SeqParams)
     with open(src, "rb") as f, lzma.open(dst, "wb", preset=preset) as out:
+        magic = f.read(8)
+        pp_size = C.sizeof(abi.PicParams) if magic == MAGIC else abi.PIC_PARAMS_SIZE_V1
+        f.seek(0)
         out.write(f.read(8 + seq_size))
         f.seek(8)
         sp = abi.SeqParams.from_buffer_copy(f.read(seq_size))
@@ -218,7 +224,7 @@ def strip_planes_and_compress(src, dst, preset=6):
                 out.write(hdr)
                 out.write(f.read(nctu * _PCM_CTU_BYTES))
                 continue
-            body = C.sizeof(abi.PicParams) + nctu * (len(_U8_FIELDS) * P + 2 * 4 * P + 2 * P + 2 * P + (16 + 4 + 4) * P * 2 + 18 * 4) + 144
+            body = pp_size + nctu * (len(_U8_FIELDS) * P + 2 * 4 * P + 2 * P + 2 * P + (16 + 4 + 4) * P * 2 + 18 * 4) + 144
             out.write(struct.pack("<4i", tag, nctu, pic_id, 0))
             out.write(f.read(body))
             if has_planes:

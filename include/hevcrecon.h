@@ -75,6 +75,10 @@ typedef struct hevcrecon_pic_params {
   int32_t num_ref[2];
   int32_t ref_pic_id[2][HEVCRECON_MAX_REFS]; /* engine picture ids of the reference pictures */
   int32_t ref_poc[2][HEVCRECON_MAX_REFS];
+  /* pps->getConstrainedIntraPred(): intra blocks use only neighbours that are themselves intra
+   * (TComPattern::is*Available, TLibCommon/TComPattern.cpp:653-830) */
+  int32_t constrained_intra_pred;
+  int32_t reserved[7];
 } hevcrecon_pic_params;
 
 /* One CTU's parsed syntax: plain pointers to the TComDataCU member arrays

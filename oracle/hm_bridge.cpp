@@ -160,6 +160,7 @@ struct Bridge {
     bool sao = sl->getSPS()->getUseSAO();
     pp.sao_luma = sao && sl->getSaoEnabledFlag();
     pp.sao_chroma = sao && sl->getSaoEnabledFlagChroma();
+    pp.constrained_intra_pred = sl->getPPS()->getConstrainedIntraPred();
     for (int l = 0; l < 2; l++) {
       pp.num_ref[l] = sl->isIntra() ? 0 : sl->getNumRefIdx(RefPicList(l));
       if (l == 1 && !sl->isInterB()) pp.num_ref[l] = 0;
@@ -283,7 +284,7 @@ struct Bridge {
     hevcrecon_seq_params sp;
     fill_seq(pic, sp);
     if (!header_written) {
-      fwrite("HVSYN1\0\0", 1, 8, dump);
+      fwrite("HVSYN2\0\0", 1, 8, dump);
       put(&sp, 1);
       header_written = true;
     }

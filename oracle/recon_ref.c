@@ -168,6 +168,19 @@ static inline int unfiltered(const hevcref_ctx *c, const hevcrecon_ctu_syntax *c
 /* z index of the partition that holds luma sample (x,y) of CTU-relative coordinates */
 static inline int zidx(const hevcref_ctx *c, int x, int y) { return c->raster_to_z[y >> 2][x >> 2]; }
 
+typedef struct {
+  const hevcrecon_ctu_syntax *ctu;
+  int z;
+} PartRef;
+
+/* Partition holding luma sample (x,y) of the picture. */
+static PartRef part_at(const hevcref_ctx *c, int x, int y) {
+  PartRef r;
+  r.ctu = &c->ctus[(y >> 6) * c->ctus_w + (x >> 6)];
+  r.z = zidx(c, x & 63, y & 63);
+  return r;
+}
+
 /* ---------------------------------------------------------------- transform -------- */
 
 /* TComTrQuant::setQPforQuant, TLibCommon/TComTrQuant.cpp:192-214 */
@@ -460,6 +473,10 @@ static void build_intra_refs(const hevcref_ctx *c, int comp, int x0, int y0, int
     }
     int ok = sx >= 0 && sy >= 0 && sx < pw && sy < ph;
     if (ok) ok = coding_order(c, (sx << sh) >> 2, (sy << sh) >> 2) < cur;
+    if (ok && c->pp->constrained_intra_pred) { /* TComPattern::is*Available with constrained intra prediction */
+      PartRef nb = part_at(c, sx << sh, sy << sh);
+      ok = nb.ctu->pred_mode[nb.z] == 1;
+    }
     avail[u] = ok;
     navail += ok;
   }
@@ -741,19 +758,6 @@ static void decompress_cu(hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int c
 }
 
 /* ---------------------------------------------------------------- deblocking ------- */
-
-typedef struct {
-  const hevcrecon_ctu_syntax *ctu;
-  int z;
-} PartRef;
-
-/* Partition holding luma sample (x,y) of the picture. */
-static PartRef part_at(const hevcref_ctx *c, int x, int y) {
-  PartRef r;
-  r.ctu = &c->ctus[(y >> 6) * c->ctus_w + (x >> 6)];
-  r.z = zidx(c, x & 63, y & 63);
-  return r;
-}
 
 /* TComLoopFilter::xGetBoundaryStrengthSingle, TLibCommon/TComLoopFilter.cpp:421-543.
  * q at (x,y); p is the partition left of / above it.  tu_edge: the edge is a transform-block edge. */

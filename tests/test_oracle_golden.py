@@ -126,3 +126,22 @@ def test_pcm_samples_are_what_makes_the_pcm_stream_match():
     ref.reconstruct(pic)
     luma = ref.download(2, pic.pic_id)[0]
     assert syntax.plane_md5(luma, seq.seq_params.bit_depth_luma) != pic.stage_md5[2][0]
+
+
+def test_constraint_is_what_makes_the_cip_stream_match():
+    """Negative control for the constrained-intra fixture: with the flag cleared, its first B picture must NOT match."""
+    import copy
+
+    seq = load_golden("cip_416x240", 2)
+    ref = RefModel(seq.seq_params)
+    ref.reconstruct(seq.pictures[0])
+    pic = copy.copy(seq.pictures[1])
+    from hevc_amd import abi
+
+    pp = abi.PicParams.from_buffer_copy(bytes(pic.pic_params))
+    assert pp.constrained_intra_pred == 1
+    pp.constrained_intra_pred = 0
+    pic.pic_params = pp
+    ref.reconstruct(pic)
+    luma = ref.download(2, pic.pic_id)[0]
+    assert syntax.plane_md5(luma, seq.seq_params.bit_depth_luma) != pic.stage_md5[2][0]

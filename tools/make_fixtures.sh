@@ -15,6 +15,7 @@ python "$root/tools/gen_clip.py" 416 240 9 1234 c240.yuv
 python "$root/tools/gen_clip.py" 1920 1080 60 20240607 c1080.yuv
 python "$root/tools/gen_clip.py" 416 240 5 1234 n240.yuv noise
 python "$root/tools/gen_clip.py" 416 240 9 1234 f240.yuv fade
+python "$root/tools/gen_clip.py" 416 240 6 1234 n6.yuv noise
 E="$root/oracle/_ref/TAppEncoder"
 for c in lowdelay_P_main randomaccess_main randomaccess_he10 intra_main; do
   $E -c $cfg/encoder_$c.cfg -i c240.yuv -wdt 416 -hgt 240 -fr 30 -f 9 -b ${c}_240.bin -o ${c}_240_rec.yuv --SEIpictureDigest=1 > ${c}_240.enc.log &
@@ -24,6 +25,8 @@ $E -c $cfg/encoder_lowdelay_P_main.cfg -i c240.yuv -wdt 416 -hgt 240 -fr 30 -f 6
 # explicit weighted prediction on the fading clip: P slices (8-bit) and B slices (10-bit)
 $E -c $cfg/encoder_lowdelay_P_main.cfg -i f240.yuv -wdt 416 -hgt 240 -fr 30 -f 9 -b wpp_240.bin -o /dev/null --SEIpictureDigest=1 -wpP 1 > wpp_240.enc.log &
 $E -c $cfg/encoder_randomaccess_he10.cfg -i f240.yuv -wdt 416 -hgt 240 -fr 30 -f 9 -b wpb_240.bin -o /dev/null --SEIpictureDigest=1 -wpP 1 -wpB 1 > wpb_240.enc.log &
+# constrained intra prediction; the noise patch yields intra blocks inside the B pictures
+$E -c $cfg/encoder_randomaccess_main.cfg -i n6.yuv -wdt 416 -hgt 240 -fr 30 -f 6 -q 30 -b cip_240.bin -o /dev/null --SEIpictureDigest=1 --ConstrainedIntraPred=1 > cip_240.enc.log &
 # IPCM: noise patch at QP 6; 10-bit with 8-bit PCM samples and the in-loop filters off for IPCM units, 8-bit with them on
 $E -c $cfg/encoder_randomaccess_he10.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 5 -q 6 -b pcm_240.bin -o /dev/null --SEIpictureDigest=1 --PCMEnabledFlag=1 --PCMFilterDisableFlag=1 > pcm_240.enc.log &
 $E -c $cfg/encoder_lowdelay_P_main.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 4 -q 6 -b pcmlf_240.bin -o /dev/null --SEIpictureDigest=1 --PCMEnabledFlag=1 --PCMFilterDisableFlag=0 > pcmlf_240.enc.log &
@@ -32,7 +35,7 @@ $E -c $cfg/encoder_randomaccess_he10.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30
 $E -c $cfg/encoder_intra_main.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 16 -b intra_main_1080.bin -o /dev/null --SEIpictureDigest=1 > intra_main_1080.enc.log &
 wait
 D="$root/oracle/_ref/TAppDecoderBridge"
-for s in lowdelay_P_main_240 randomaccess_main_240 randomaccess_he10_240 intra_main_240 scalinglist_240 lossless_240 pcm_240 pcmlf_240 wpp_240 wpb_240 ra_main_1080 ra_he10_1080 intra_main_1080; do
+for s in lowdelay_P_main_240 randomaccess_main_240 randomaccess_he10_240 intra_main_240 scalinglist_240 lossless_240 pcm_240 pcmlf_240 wpp_240 wpb_240 cip_240 ra_main_1080 ra_he10_1080 intra_main_1080; do
   HEVCRECON_MODE=dump HEVCRECON_DUMP=$s.syn $D -b $s.bin > $s.dec.log
 done
 cd "$root" && python - <<'PY'
@@ -41,7 +44,7 @@ from hevc_amd import syntax
 names = {"lowdelay_P_main_240": "lowdelay_P_main_416x240", "randomaccess_main_240": "randomaccess_main_416x240",
          "randomaccess_he10_240": "randomaccess_he10_416x240", "intra_main_240": "intra_main_416x240",
          "scalinglist_240": "scalinglist_416x240", "lossless_240": "lossless_416x240",
-         "pcm_240": "pcm_416x240", "pcmlf_240": "pcmlf_416x240", "wpp_240": "wpp_416x240", "wpb_240": "wpb_416x240",
+         "pcm_240": "pcm_416x240", "pcmlf_240": "pcmlf_416x240", "wpp_240": "wpp_416x240", "wpb_240": "wpb_416x240", "cip_240": "cip_416x240",
          "ra_main_1080": "randomaccess_main_1920x1080", "ra_he10_1080": "randomaccess_he10_1920x1080",
          "intra_main_1080": "intra_main_1920x1080"}
 keys = {"ra_main_1080": "randomaccess_main_1080", "ra_he10_1080": "randomaccess_he10_1080"}
@@ -56,7 +59,7 @@ for src, dst in names.items():
             rows.append([int(m.group(1)), m.group(2), m.group(3), m.group(4)])
     md5[keys.get(src, src)] = rows
 json.dump(md5, open("tests/golden/hm_md5.json", "w"), indent=0)
-for b in ["lowdelay_P_main_240", "randomaccess_main_240", "randomaccess_he10_240", "intra_main_240", "scalinglist_240", "lossless_240", "pcm_240", "pcmlf_240", "wpp_240", "wpb_240"]:
+for b in ["lowdelay_P_main_240", "randomaccess_main_240", "randomaccess_he10_240", "intra_main_240", "scalinglist_240", "lossless_240", "pcm_240", "pcmlf_240", "wpp_240", "wpb_240", "cip_240"]:
     shutil.copy("work/%s.bin" % b, "tests/golden/%s.bin" % b)
 shutil.copy("work/ra_main_1080.bin", "tests/golden/randomaccess_main_1080.bin")
 PY
