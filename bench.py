@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--contexts", type=int, default=1, help="engine contexts (HIP streams) the streams of this GPU are spread over")
     ap.add_argument("--fixture", default="randomaccess_main_1920x1080")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-handover", action="store_true", help="skip the passes that time the syntax hand-over")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -224,6 +225,32 @@ def main():
     except (OSError, ValueError):
         pass
 
+    # ---- syntax hand-over (untimed for `value`): the packed pictures cross the host link again ----
+    # (a) copies + expansion alone; (b) one step with every batch's pictures uploaded before it is reconstructed
+    # (uploads run on each context's copy stream and overlap the previous batch's kernels).  One host thread
+    # issues all of it here; a deployment has one host decoder per stream doing its own hand-over.
+    handover = None
+    if not args.no_handover:
+        up_bytes = sum(syns[t][0].stats()[29] for t in range(npic))
+        sync()
+        t0 = time.perf_counter()
+        for t in range(npic):
+            for s in range(S):
+                syns[t][s].upload()
+        sync()
+        t_up = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for t in range(npic):
+            for s in range(S):
+                syns[t][s].upload()
+            for c in range(C):
+                engs[c].reconstruct_prepared(prepared[t][c])
+        sync()
+        t_both = time.perf_counter() - t0
+        handover = {"bytes_per_frame": up_bytes // npic, "copy_only_frames_per_s": round(npic * S / t_up, 1),
+                    "copy_only_gbps": round(up_bytes * S / t_up / 1e9, 2),
+                    "with_reconstruction_frames_per_s": round(npic * S / t_both, 1)}
+
     frames_total = npic * S * args.steps * world
     value = frames_total / elapsed
     result = {
@@ -251,6 +278,8 @@ def main():
                      "launches_per_step": int(dom_launches), "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 3)},
         "kernels": kernels,
     }
+    if handover is not None:
+        result["handover"] = handover
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:

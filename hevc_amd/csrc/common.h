@@ -3,7 +3,10 @@
 // Everything a picture needs lives in HBM in a few flat arrays, written once by the host packer
 // (packer.cpp) and read by every kernel:
 //   * Part4   rec4[(H/4)*(W/4)]  one 16-byte record per 4x4 luma block, RASTER order over the picture
-//                                (the reference keeps these per CTU in z-order: TLibCommon/TComDataCU.h:122-204)
+//                                (the reference keeps these per CTU in z-order: TLibCommon/TComDataCU.h:122-204).
+//                                It crosses the host link run-length coded (runs[] + ctu_run_off[]: consecutive
+//                                units of a CTU, in z-order, with identical records) and is expanded on the device
+//                                by k_expand, the first kernel of the first batch that uses the picture
 //   * TuItem  tu[4][...]         one entry per coded transform block, grouped by size 4/8/16/32
 //   * int16   coeff[...]         coded coefficients, raster inside a block, blocks back to back
 //   * IntraItem intra[...]       one entry per intra prediction block, grouped by CTU, inside a CTU by local
@@ -37,9 +40,9 @@ struct __attribute__((aligned(16))) Part4 {
   uint8_t flags;
   uint8_t tu;
   int8_t qp;
-  uint8_t pad;
+  uint8_t pad;     /* in a run: z index of the run's first unit inside its CTU; 0 in rec4 */
   int8_t ref_idx[2];
-  uint8_t pad2[2];
+  uint8_t pad2[2]; /* in a run: pad2[0] = units in the run - 1; 0 in rec4 */
   int16_t mv[2][2]; /* [list][hor, ver], quarter luma samples, exactly as parsed (unused lists too) */
 };
 
@@ -71,6 +74,11 @@ struct McTile {
 struct McBlk {
   uint16_t x, y; /* luma position of the region */
 };
+
+// Capacity of the intra kernel's per-CTU tables.  A 64x64 CTU holds at most 256 luma + 2 x 64 chroma 4x4 blocks, and
+// its longest dependency chain (all blocks 4x4) has 90 links; the packer refuses anything beyond.
+#define HR_INTRA_MAX_ITEMS 384
+#define HR_INTRA_MAX_LEVELS 96
 
 #define IN_CORNER 0x01
 #define IN_HAS_RESI 0x02
@@ -137,6 +145,9 @@ struct PicJob {
   const void *ref[2][HR_MAX_REFS][3]; /* reference pictures (final planes) */
   int32_t ref_poc[2][HR_MAX_REFS];
   const Part4 *rec4;
+  const Part4 *runs;           /* rec4 run-length coded, as uploaded */
+  const uint32_t *ctu_run_off; /* first run of every CTU, + the total */
+  int32_t need_expand;         /* rec4 has not been expanded from the runs since the last upload */
   const McTile *mc_tile[3]; /* 64x64, 32x32, 16x16 */
   const McBlk *mc_blk;
   int32_t n_mc_tile[3], n_mc_blk;
@@ -165,6 +176,7 @@ struct PicJob {
 
 // Kernel classes for the per-kernel timers (hevcrecon_profile_read).
 // K_INTER is also the launch kind of all four inter kernels; its timer slot holds the 64x64 tile kernel.
+// K_OTHER holds k_expand.
 enum { K_INTER = 0, K_TRANSFORM, K_INTRA, K_DEBLOCK_V, K_DEBLOCK_H, K_SAO, K_COPY, K_OTHER, K_INTER_T32, K_INTER_T16, K_INTER_BLK, K_COUNT };
 
 #endif

@@ -40,6 +40,7 @@ struct Interval {
 struct hevcrecon_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // syntax uploads (+ their expansion) run beside the reconstruction kernels
   bool have_seq = false;
   hevcrecon_seq_params sp;
   SeqInfo si;
@@ -55,6 +56,15 @@ struct hevcrecon_ctx {
   PicJob *jobs_dev = nullptr;
   hipEvent_t ring_ev[kRing];
   bool ring_used[kRing];
+  // "batch done" events: slot b % kRing is recorded behind batch b's last kernel.  A later batch's event in the
+  // same slot also implies batch b is done (one stream), so waiting on the slot is always sufficient.
+  hipEvent_t batch_ev[kRing];
+  int64_t batch_no = 0;
+  // Cross-stream waits are expensive, and both streams run in order: the main stream waits for an upload only
+  // when it is newer than the newest one it has already waited for, and the copy stream likewise for batches.
+  int64_t upload_no = 0, upload_waited = -1, upload_synced = -1, batch_waited = -1;
+  hipEvent_t copy_ev[kRing];  // recorded on the copy stream when the main stream has to wait for uploads
+  int copy_ev_pos = 0;
   int ring_pos = 0;
   int32_t *error_flag_dev = nullptr;
   void *dl_host = nullptr;  // pinned staging for downloads / uploads
@@ -75,6 +85,10 @@ struct hevcrecon_syntax {
   size_t dev_cap = 0;
   char *host = nullptr;  // pinned staging
   size_t host_cap = 0;
+  size_t upload_bytes = 0, off_runs = 0, off_runoff = 0;
+  bool expanded = false;       // rec4 has been expanded from the uploaded runs
+  int64_t last_batch = -1;     // last batch whose kernels read the device copy
+  int64_t upload_seq = -1;     // position of the last upload in the copy stream
   size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_mct[3] = {0, 0, 0}, off_mcb = 0, off_scal = 0, off_wp = 0;
   bool uploaded = false;
   std::string err;
@@ -249,10 +263,13 @@ extern "C" int hevcrecon_create(hevcrecon_ctx **out, int device) {
   std::memset(c->launches, 0, sizeof(c->launches));
   std::memset(c->ring_used, 0, sizeof(c->ring_used));
   bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+  ok = ok && hipStreamCreate(&c->copy_stream) == hipSuccess;
   ok = ok && hipHostMalloc((void **)&c->jobs_host, sizeof(PicJob) * HR_MAX_BATCH * kRing) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->jobs_dev, sizeof(PicJob) * HR_MAX_BATCH * kRing) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->error_flag_dev, 64) == hipSuccess;
   for (int i = 0; ok && i < kRing; i++) ok = hipEventCreate(&c->ring_ev[i]) == hipSuccess;
+  for (int i = 0; ok && i < kRing; i++) ok = hipEventCreateWithFlags(&c->batch_ev[i], hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < kRing; i++) ok = hipEventCreateWithFlags(&c->copy_ev[i], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     delete c;
     return 3;
@@ -277,11 +294,14 @@ extern "C" void hevcrecon_destroy(hevcrecon_ctx *c) {
   free_picture(c->stage[1]);
   for (size_t i = 0; i < c->event_pool.size(); i++) hipEventDestroy(c->event_pool[i]);
   for (int i = 0; i < kRing; i++) hipEventDestroy(c->ring_ev[i]);
+  for (int i = 0; i < kRing; i++) hipEventDestroy(c->batch_ev[i]);
+  for (int i = 0; i < kRing; i++) hipEventDestroy(c->copy_ev[i]);
   if (c->jobs_host) hipHostFree(c->jobs_host);
   if (c->jobs_dev) hipFree(c->jobs_dev);
   if (c->error_flag_dev) hipFree(c->error_flag_dev);
   if (c->dl_host) hipHostFree(c->dl_host);
   hipStreamDestroy(c->stream);
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   delete c;
 }
 
@@ -349,6 +369,7 @@ extern "C" void hevcrecon_syntax_destroy(hevcrecon_syntax *s) {
   if (!s) return;
   if (s->ctx) {
     hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->copy_stream);
     hipStreamSynchronize(s->ctx->stream);
   }
   if (s->dev) hipFree(s->dev);
@@ -361,10 +382,18 @@ extern "C" int hevcrecon_syntax_begin(hevcrecon_syntax *s) {
   if (s->ctx) {
     if (!s->ctx->have_seq) return fail(s->ctx, "no sequence parameters");
     s->si = s->ctx->si;
-    // the previous upload from the staging buffer must have left the host before it is rewritten
-    if (s->uploaded) hipStreamSynchronize(s->ctx->stream);
+    // the previous upload must have left the staging buffer, and the kernels that read the previous picture's
+    // device copy must be done, before either is rewritten
+    if (s->uploaded) {
+      if (s->upload_seq > s->ctx->upload_synced) {
+        hipStreamSynchronize(s->ctx->copy_stream);
+        s->ctx->upload_synced = s->ctx->upload_no - 1;
+      }
+      if (s->last_batch >= 0) hipEventSynchronize(s->ctx->batch_ev[s->last_batch % kRing]);
+    }
   }
   s->uploaded = false;
+  s->last_batch = -1;
   s->pk.begin(s->si);
   return 0;
 }
@@ -406,6 +435,17 @@ extern "C" int hevcrecon_syntax_add_ctu(hevcrecon_syntax *s, int ctu_addr, const
   return 0;
 }
 
+// Copy of the packed picture to the device, on the copy stream (nothing but copies runs there, so uploads never
+// queue behind kernels).  The run-length coded motion records are expanded by the first batch that uses them.
+static int queue_upload(hevcrecon_syntax *s) {
+  hevcrecon_ctx *c = s->ctx;
+  HIPCHK(c, hipMemcpyAsync(s->dev, s->host, s->upload_bytes, hipMemcpyHostToDevice, c->copy_stream));
+  s->upload_seq = c->upload_no++;
+  s->uploaded = true;
+  s->expanded = false;
+  return 0;
+}
+
 extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_params *pp) {
   if (!s || !pp) return 1;
   if (!s->pk.finish(pp)) {
@@ -422,7 +462,8 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
     off = align_up(off + bytes, 256);
     return o;
   };
-  s->off_rec4 = place(k.rec4.size() * sizeof(Part4));
+  s->off_runs = place(k.runs.size() * sizeof(Part4));
+  s->off_runoff = place(k.ctu_run_off.size() * sizeof(uint32_t));
   for (int i = 0; i < 4; i++) s->off_tu[i] = place(k.tu[i].size() * sizeof(TuItem));
   s->off_coeff = place(k.coeff.size() * sizeof(int16_t));
   s->off_intra = place(k.intra.size() * sizeof(IntraItem));
@@ -435,8 +476,11 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   s->off_scal = place(sizeof(ScalingTables));
   s->off_wp = place(sizeof(WpTables));
   const size_t upload_bytes = off;
+  s->upload_bytes = upload_bytes;
+  s->off_rec4 = place(k.rec4.size() * sizeof(Part4));  // device only: expanded from the runs after the copy
   const size_t total = off;
   if (s->dev_cap < total) {
+    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (s->dev) hipFree(s->dev);
     s->dev = nullptr;
@@ -453,7 +497,8 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
     HIPCHK(c, hipHostMalloc((void **)&s->host, cap));
     s->host_cap = cap;
   }
-  std::memcpy(s->host + s->off_rec4, k.rec4.data(), k.rec4.size() * sizeof(Part4));
+  std::memcpy(s->host + s->off_runs, k.runs.data(), k.runs.size() * sizeof(Part4));
+  std::memcpy(s->host + s->off_runoff, k.ctu_run_off.data(), k.ctu_run_off.size() * sizeof(uint32_t));
   for (int i = 0; i < 4; i++) std::memcpy(s->host + s->off_tu[i], k.tu[i].data(), k.tu[i].size() * sizeof(TuItem));
   std::memcpy(s->host + s->off_coeff, k.coeff.data(), k.coeff.size() * sizeof(int16_t));
   std::memcpy(s->host + s->off_intra, k.intra.data(), k.intra.size() * sizeof(IntraItem));
@@ -465,9 +510,21 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   std::memcpy(s->host + s->off_mcb, k.mc_blk.data(), k.mc_blk.size() * sizeof(McBlk));
   std::memcpy(s->host + s->off_scal, &k.scaling, sizeof(ScalingTables));
   std::memcpy(s->host + s->off_wp, &k.wp, sizeof(WpTables));
-  HIPCHK(c, hipMemcpyAsync(s->dev, s->host, upload_bytes, hipMemcpyHostToDevice, c->stream));
-  s->uploaded = true;
-  return 0;
+  return queue_upload(s);
+}
+
+// No counterpart in the reference: queues the host-to-device copy of an already packed picture again
+// (hevcrecon_syntax_finish does it once).  For hosts that keep packed pictures and for measuring the hand-over.
+extern "C" int hevcrecon_syntax_upload(hevcrecon_syntax *s) {
+  if (!s) return 1;
+  if (!s->ctx || !s->pk.finished || !s->dev) return fail(s->ctx, "nothing to upload: the picture is not finished on a context");
+  HIPCHK(s->ctx, hipSetDevice(s->ctx->device));
+  // kernels already queued may still read the device copy that is about to be rewritten
+  if (s->last_batch > s->ctx->batch_waited) {
+    HIPCHK(s->ctx, hipStreamWaitEvent(s->ctx->copy_stream, s->ctx->batch_ev[s->last_batch % kRing], 0));
+    s->ctx->batch_waited = s->last_batch;
+  }
+  return queue_upload(s);
 }
 
 extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[32]) {
@@ -499,6 +556,8 @@ extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[32]
   int64_t intra4 = 0;
   for (size_t i = 0; i < k.rec4.size(); i++) intra4 += (k.rec4[i].flags & P4_INTRA) ? 1 : 0;
   out[9] = intra4;
+  out[29] = (int64_t)s->upload_bytes;
+  out[30] = (int64_t)k.runs.size();
   out[10] = k.finished ? 1 : 0;
   // intra schedule: rounds of 4 blocks on the critical path (slowest CTU of every wave) and in total
   if (k.finished && !k.wave_off.empty()) {
@@ -574,7 +633,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
   PicJob *jh = c->jobs_host + (size_t)slot * HR_MAX_BATCH;
   PicJob *jd = c->jobs_dev + (size_t)slot * HR_MAX_BATCH;
   int max_tu[4] = {0, 0, 0, 0}, max_levels = 0, max_mct[3] = {0, 0, 0}, max_mcb = 0;
-  bool any_deblock = false, any_sao = false, any_wp = false;
+  bool any_deblock = false, any_sao = false, any_wp = false, any_expand = false;
   for (int i = 0; i < n; i++) {
     hevcrecon_syntax *y = syn[i];
     const PackedPicture &k = y->pk;
@@ -596,6 +655,11 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
         j.ref_poc[l][r] = k.pp.ref_poc[l][r];
       }
     j.rec4 = (const Part4 *)(y->dev + y->off_rec4);
+    j.runs = (const Part4 *)(y->dev + y->off_runs);
+    j.ctu_run_off = (const uint32_t *)(y->dev + y->off_runoff);
+    j.need_expand = y->expanded ? 0 : 1;
+    any_expand = any_expand || !y->expanded;
+    y->expanded = true;
     for (int t = 0; t < 3; t++) {
       j.mc_tile[t] = (const McTile *)(y->dev + y->off_mct[t]);
       j.n_mc_tile[t] = (int)k.mc_tile[t].size();
@@ -636,10 +700,25 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     j.error_flag = c->error_flag_dev;
     any_deblock = any_deblock || !k.pp.deblocking_disable;
   }
+  {  // device copies complete: one event behind everything the copy stream holds covers the whole batch
+    bool wait = false;
+    for (int i = 0; i < n; i++) wait = wait || syn[i]->upload_seq > c->upload_waited;
+    if (wait) {
+      hipEvent_t e = c->copy_ev[c->copy_ev_pos];
+      c->copy_ev_pos = (c->copy_ev_pos + 1) % kRing;
+      HIPCHK(c, hipEventRecord(e, c->copy_stream));
+      HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
+      c->upload_waited = c->upload_no - 1;
+    }
+  }
   HIPCHK(c, hipMemcpyAsync(jd, jh, sizeof(PicJob) * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipEventRecord(c->ring_ev[slot], c->stream));
   c->ring_used[slot] = true;
   // ---- launches ----
+  if (any_expand) {
+    Timed tm(c, K_OTHER, 1);
+    hr_launch(K_OTHER, jd, n, s, c->stream, 0, 0);
+  }
   if (max_mct[0] > 0 || max_mct[1] > 0 || max_mct[2] > 0 || max_mcb > 0) {
     // arg = 0..2: uniform regions of 64, 32, 16 samples; 3: the mixed rest; +4: the variants with explicit weights
     const int cls[4] = {K_INTER, K_INTER_T32, K_INTER_T16, K_INTER_BLK};
@@ -697,6 +776,9 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     hr_launch(K_SAO, jd, n, s, c->stream, 0, 0);
   }
   HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->batch_ev[c->batch_no % kRing], c->stream));
+  for (int i = 0; i < n; i++) syn[i]->last_batch = c->batch_no;
+  c->batch_no++;
   for (int i = 0; i < n; i++) {
     c->pics[dst_ids[i]].valid = true;
     c->pics[dst_ids[i]].poc = syn[i]->pk.pp.poc;
@@ -783,6 +865,8 @@ extern "C" int hevcrecon_picture_release(hevcrecon_ctx *c, int pic_id) {
 extern "C" int hevcrecon_synchronize(hevcrecon_ctx *c) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+  c->upload_synced = c->upload_no - 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -812,6 +896,6 @@ extern "C" int hevcrecon_profile_read(hevcrecon_ctx *c, double ms_out[HEVCRECON_
 
 extern "C" const char *hevcrecon_kernel_name(int idx) {
   static const char *names[K_COUNT] = {"k_inter_tile64", "k_transform", "k_intra",        "k_deblock_v",    "k_deblock_h", "k_sao",
-                                       "stage_copy",     "other",       "k_inter_tile32", "k_inter_tile16", "k_inter_blk"};
+                                       "stage_copy",     "k_expand",    "k_inter_tile32", "k_inter_tile16", "k_inter_blk"};
   return idx >= 0 && idx < K_COUNT ? names[idx] : "";
 }

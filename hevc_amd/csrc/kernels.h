@@ -5,7 +5,8 @@
 
 // Launches kernel class `kind` (K_* of common.h) for a batch of `n` pictures described by the device
 // array `jobs`.  arg/arg2: K_TRANSFORM: log2 block size, max blocks of that size over the batch;
-// K_INTRA: CTU wave, max CTUs of that wave over the batch.
+// K_INTRA: CTU wave, max CTUs of that wave over the batch.  K_OTHER: expansion of the run-length coded motion
+// records of the pictures whose need_expand is set.
 void hr_launch(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t stream, int arg, int arg2);
 
 #endif

@@ -1014,8 +1014,8 @@ __device__ __forceinline__ int intra_ang_neg(const int *cn, int sgn, int inv, in
 #define IT_NTHR (IT_WAVES * 64)
 #define IT_YW 100 /* luma tile row: x = -1 .. 96 (97 used) */
 #define IT_CW 52  /* chroma tile row: x = -1 .. 48 (49 used) */
-#define IT_MAX_ITEMS 384
-#define IT_MAX_LEVELS 96
+#define IT_MAX_ITEMS HR_INTRA_MAX_ITEMS
+#define IT_MAX_LEVELS HR_INTRA_MAX_LEVELS
 
 template <typename pel_t>
 __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s, int wave_idx) {
@@ -1701,6 +1701,41 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_expand: run-length coded motion records -> rec4.  One workgroup per CTU, one lane per 4x4 unit.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_expand(const PicJob *jobs, SeqInfo s) {
+  __shared__ uint8_t start_s[256];
+  const PicJob &J = jobs[blockIdx.y];
+  if (!J.need_expand) return;
+  const Part4 *runs = J.runs;
+  const uint32_t *ctu_run_off = J.ctu_run_off;
+  Part4 *rec4 = const_cast<Part4 *>(J.rec4);
+  const int ctu = blockIdx.x, z = threadIdx.x;
+  const unsigned first = ctu_run_off[ctu], n = ctu_run_off[ctu + 1] - first;
+  if ((unsigned)z < n) start_s[z] = runs[first + z].pad;
+  __syncthreads();
+  int x = 0, y = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    x |= ((z >> (2 * b)) & 1) << b;
+    y |= ((z >> (2 * b + 1)) & 1) << b;
+  }
+  const int ux = (ctu % s.ctus_w) * 16 + x, uy = (ctu / s.ctus_w) * 16 + y;
+  if (ux >= s.uw || uy >= s.uh || n == 0) return;
+  // last run that starts at or before z (runs of a CTU are sorted by their first unit; at most 256 of them)
+  int lo = 0, hi = (int)n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (start_s[mid] <= z) lo = mid; else hi = mid - 1;
+  }
+  Part4 r = runs[first + lo];
+  if (z < r.pad || z > r.pad + r.pad2[0]) return;  // not covered: cannot happen with a well-formed list
+  r.pad = 0;
+  r.pad2[0] = 0;
+  rec4[(size_t)uy * s.uw + ux] = r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 #define LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
@@ -1737,6 +1772,9 @@ static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, 
     case K_INTRA:
       // arg = CTU wave, arg2 = max number of CTUs in that wave over the batch
       LAUNCH(k_intra<pel_t>, dim3(arg2, n), dim3(IT_NTHR), st, jobs, s, arg);
+      break;
+    case K_OTHER:
+      LAUNCH(k_expand, dim3(s.ctus_w * s.ctus_h, n), dim3(256), st, jobs, s);
       break;
     case K_DEBLOCK_V:
       LAUNCH((k_deblock<pel_t, 0>), dim3(((s.w / 8) * s.uh + 255) / 256, n), dim3(256), st, jobs, s);

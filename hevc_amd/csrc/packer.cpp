@@ -93,6 +93,10 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
     // blocks of one local level are independent of each other: order the CTU's blocks by level
     int nlev = 0;
     for (size_t i = 0; i < ctu_item_lvl.size(); i++) nlev = std::max<int>(nlev, ctu_item_lvl[i]);
+    if (nlev > HR_INTRA_MAX_LEVELS || ctu_items.size() > HR_INTRA_MAX_ITEMS) {
+      error = "CTU holds more intra blocks or dependency levels than a 64x64 CTU can";
+      return false;
+    }
     std::vector<int> start(nlev + 2, 0);
     for (size_t i = 0; i < ctu_item_lvl.size(); i++) start[ctu_item_lvl[i] + 1]++;
     IntraCtu ic;
@@ -380,6 +384,7 @@ bool PackedPicture::finish(const hevcrecon_pic_params *p) {
   for (size_t i = 0; i < ictu.size(); i++) sorted[cursor[ictu_wave[i] - 1]++] = ictu[i];
   ictu.swap(sorted);
   build_mc_lists();
+  build_runs();
   finished = true;
   return true;
 }
@@ -474,6 +479,40 @@ void PackedPicture::build_mc_lists() {
   if (pp.slice_type == 2) return;
   for (int cy = 0; cy < seq.ctus_h; cy++)
     for (int cx = 0; cx < seq.ctus_w; cx++) split_mc(cx * 64, cy * 64, 0);
+}
+
+void PackedPicture::build_runs() {
+  runs.clear();
+  ctu_run_off.assign((size_t)seq.ctus_w * seq.ctus_h + 1, 0);
+  for (int cy = 0; cy < seq.ctus_h; cy++)
+    for (int cx = 0; cx < seq.ctus_w; cx++) {
+      ctu_run_off[(size_t)cy * seq.ctus_w + cx] = (uint32_t)runs.size();
+      bool open = false;  // the last run can still grow (its successor in z-order is the next unit visited)
+      for (int z = 0; z < 256; z++) {
+        const int ux = cx * 16 + kZ.x[z], uy = cy * 16 + kZ.y[z];
+        if (ux >= seq.uw || uy >= seq.uh) {
+          open = false;
+          continue;
+        }
+        const Part4 &p = rec4[(size_t)uy * seq.uw + ux];
+        if (open) {
+          Part4 &r = runs.back();
+          Part4 probe = r;
+          probe.pad = 0;
+          probe.pad2[0] = 0;
+          if (std::memcmp(&probe, &p, sizeof(Part4)) == 0) {
+            r.pad2[0]++;
+            continue;
+          }
+        }
+        Part4 r = p;
+        r.pad = (uint8_t)z;
+        r.pad2[0] = 0;
+        runs.push_back(r);
+        open = true;
+      }
+    }
+  ctu_run_off.back() = (uint32_t)runs.size();
 }
 
 int64_t PackedPicture::algorithmic_bytes() const {

@@ -36,6 +36,11 @@ struct PackedPicture {
   std::string error;
 
   // scratch
+  // rec4 as it crosses the host link: runs of identical records along the z-order of each CTU (in-picture units
+  // only), and the index of every CTU's first run (+ the total)
+  std::vector<Part4> runs;
+  std::vector<uint32_t> ctu_run_off;
+  void build_runs();
   std::vector<IntraItem> ctu_items;   // intra blocks of the CTU being added, in coding order
   std::vector<uint16_t> ctu_item_lvl; // their local levels
   // Per intra block, which of its available neighbour units are themselves intra (same bit layout as

@@ -44,6 +44,10 @@ class Syntax:
         self.lib.hevcrecon_syntax_stats(self.h, out)
         return list(out)
 
+    def upload(self):
+        """Queue the host-to-device copy of the packed picture again (pack() queued it once)."""
+        self.engine._check(self.lib.hevcrecon_syntax_upload(self.h), "hevcrecon_syntax_upload")
+
     def algorithmic_bytes(self):
         return int(self.lib.hevcrecon_syntax_algorithmic_bytes(self.h))
 

@@ -165,7 +165,8 @@ int hevcrecon_syntax_create_detached(const hevcrecon_seq_params *sp, hevcrecon_s
  * of every wave), [14] intra rounds in total, [15] dependency levels on the critical path,
  * [16..18] motion-compensation regions predicted as one block (64x64, 32x32, 16x16), [19] 16x16 regions predicted
  * unit by unit, [20..22] reference blocks read by the regions of [16..18] (one per list in use),
- * [23..25] luma samples those regions cover inside the picture, [26..28] the same weighted by lists in use. */
+ * [23..25] luma samples those regions cover inside the picture, [26..28] the same weighted by lists in use,
+ * [29] bytes copied to the device for this picture, [30] runs the 4x4 records were coded into. */
 int hevcrecon_syntax_stats(const hevcrecon_syntax *syn, int64_t out[32]);
 
 /* Start a new picture in `syn` (drops whatever it held).  Stands where TDecTop::xDecodeSlice
@@ -194,6 +195,11 @@ int hevcrecon_syntax_add_ctu(hevcrecon_syntax *syn, int ctu_addr, const hevcreco
 
 /* Closes the picture and queues the host-to-device copy of the packed syntax. */
 int hevcrecon_syntax_finish(hevcrecon_syntax *syn, const hevcrecon_pic_params *pp);
+
+/* No counterpart in the reference.  Queues the host-to-device copy of an already finished picture again
+ * (hevcrecon_syntax_finish queues it once): for hosts that keep packed pictures around, and for measuring the
+ * hand-over.  Copies run on a stream of their own and overlap reconstruction of other pictures. */
+int hevcrecon_syntax_upload(hevcrecon_syntax *syn);
 
 /* ---- reconstruction ---------------------------------------------------- */
 
