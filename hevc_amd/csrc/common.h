@@ -8,7 +8,8 @@
 //                                units of a CTU, in z-order, with identical records) and is expanded on the device
 //                                by k_expand, the first kernel of the first batch that uses the picture
 //   * TuItem  tu[4][...]         one entry per coded transform block, grouped by size 4/8/16/32
-//   * int16   coeff[...]         coded coefficients, raster inside a block, blocks back to back
+//   * uint32  coeff[...]         coded coefficients, sparse: per block the number of non-zero coefficients, then one
+//                                word (raster position | value << 16) for each
 //   * IntraItem intra[...]       one entry per intra prediction block, grouped by CTU, inside a CTU by local
 //                                dependency level; IntraCtu ictu[...] one entry per CTU that holds intra blocks,
 //                                sorted by CTU wave (a CTU's wave is one more than the highest wave among the
@@ -59,7 +60,7 @@ struct TuItem {
   uint8_t flags;
   int8_t qp;         /* luma QP of the coding unit */
   uint8_t pad;
-  uint32_t coeff_off; /* index of the block's first coefficient in coeff[] (and of its residual in resi[]) */
+  uint32_t coeff_off; /* index of the block's header word in coeff[] */
 };
 
 // Motion compensation work lists.  Square luma regions (a whole CTU, else its 32x32 quadrants, else their 16x16
@@ -153,7 +154,7 @@ struct PicJob {
   int32_t n_mc_tile[3], n_mc_blk;
   const TuItem *tu[4];
   int32_t n_tu[4];
-  const int16_t *coeff;
+  const uint32_t *coeff; /* sparse: per block a count, then (position | value << 16) words */
   int16_t *resi[3]; /* residual of intra blocks, picture-shaped planes (same strides as the sample planes);
                        only positions covered by a coded intra block are ever written or read */
   const IntraItem *intra;

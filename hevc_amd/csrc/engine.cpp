@@ -465,7 +465,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   s->off_runs = place(k.runs.size() * sizeof(Part4));
   s->off_runoff = place(k.ctu_run_off.size() * sizeof(uint32_t));
   for (int i = 0; i < 4; i++) s->off_tu[i] = place(k.tu[i].size() * sizeof(TuItem));
-  s->off_coeff = place(k.coeff.size() * sizeof(int16_t));
+  s->off_coeff = place(k.coeff.size() * sizeof(uint32_t));
   s->off_intra = place(k.intra.size() * sizeof(IntraItem));
   s->off_ictu = place(k.ictu.size() * sizeof(IntraCtu));
   s->off_lvlc = place(k.lvl_counts.size() * sizeof(uint16_t));
@@ -500,7 +500,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   std::memcpy(s->host + s->off_runs, k.runs.data(), k.runs.size() * sizeof(Part4));
   std::memcpy(s->host + s->off_runoff, k.ctu_run_off.data(), k.ctu_run_off.size() * sizeof(uint32_t));
   for (int i = 0; i < 4; i++) std::memcpy(s->host + s->off_tu[i], k.tu[i].data(), k.tu[i].size() * sizeof(TuItem));
-  std::memcpy(s->host + s->off_coeff, k.coeff.data(), k.coeff.size() * sizeof(int16_t));
+  std::memcpy(s->host + s->off_coeff, k.coeff.data(), k.coeff.size() * sizeof(uint32_t));
   std::memcpy(s->host + s->off_intra, k.intra.data(), k.intra.size() * sizeof(IntraItem));
   std::memcpy(s->host + s->off_ictu, k.ictu.data(), k.ictu.size() * sizeof(IntraCtu));
   std::memcpy(s->host + s->off_lvlc, k.lvl_counts.data(), k.lvl_counts.size() * sizeof(uint16_t));
@@ -546,7 +546,8 @@ extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[32]
     }
   }
   out[19] = (int64_t)k.mc_blk.size();
-  out[4] = (int64_t)k.coeff.size();
+  out[4] = k.coded_coeffs;
+  out[31] = (int64_t)k.coeff.size() * 4;
   out[5] = (int64_t)k.intra.size();
   out[6] = k.wave_off.empty() ? 0 : (int64_t)k.wave_off.size() - 1;
   out[11] = (int64_t)k.ictu.size();
@@ -673,7 +674,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
       j.n_tu[t] = (int)k.tu[t].size();
       if (j.n_tu[t] > max_tu[t]) max_tu[t] = j.n_tu[t];
     }
-    j.coeff = (const int16_t *)(y->dev + y->off_coeff);
+    j.coeff = (const uint32_t *)(y->dev + y->off_coeff);
     for (int p = 0; p < 3; p++) j.resi[p] = (int16_t *)((char *)c->work_resi[i] + c->resi_off[p]);
     j.intra = (const IntraItem *)(y->dev + y->off_intra);
     j.ictu = (const IntraCtu *)(y->dev + y->off_ictu);

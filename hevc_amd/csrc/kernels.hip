@@ -873,7 +873,7 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
   const int iq = rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72;
   const int scale = iq << per;
   const int shift = bd + LOG2N - 9, add = 1 << (shift - 1);
-  const int16_t *coef = J.coeff + it.coeff_off;
+  const uint32_t *coef = J.coeff + it.coeff_off;  // header word, then the block's non-zero coefficients
   const bool tskip = (it.flags & TU_TSKIP) != 0;
   // lossless coding unit (TComTrQuant::invtransformNxN, TLibCommon/TComTrQuant.cpp:1269-1279): residual = coefficients
   // IPCM coding unit (TDecCu::xDecodePCMTexture, TLibDecoder/TDecCu.cpp:798-837): the block holds samples, not coefficients
@@ -885,10 +885,22 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
   int acc[N];
 #pragma unroll
   for (int y = 0; y < N; y++) acc[y] = 0;
-  // the whole coefficient column is fetched before the first row is used (one trip to memory, not N)
+  // The block's non-zero coefficients are scattered into a cleared LDS tile (the N lanes of the block share the
+  // list), then every lane picks up its column.  Afterwards lane c only ever writes column c again before the
+  // barrier ahead of pass 2, so the tile can be reused for the intermediate without another barrier.
+#pragma unroll
+  for (int k = 0; k < N; k++) tmp[t_local][k][c] = 0;
+  const int nnz = live ? (int)coef[0] : 0;
+  __syncthreads();
+  for (int e = c; e < nnz; e += N) {
+    const unsigned w = coef[1 + e];
+    const int pos = (int)(w & 0xffffu);
+    tmp[t_local][pos >> LOG2N][pos & (N - 1)] = (int)(int16_t)(w >> 16);
+  }
+  __syncthreads();
   int dq[N];
 #pragma unroll
-  for (int k = 0; k < N; k++) dq[k] = live ? (int)coef[k * N + c] : 0;
+  for (int k = 0; k < N; k++) dq[k] = tmp[t_local][k][c];
   // Scaling lists (TComTrQuant::xDeQuant, scaling-list branch, TLibCommon/TComTrQuant.cpp:1142-1173): the lane's
   // column meets at most 8 different matrix entries (one per matrix row; a 16x16 / 32x32 entry spans 2 / 4 rows)
   const ScalingTables *sl = J.scaling;

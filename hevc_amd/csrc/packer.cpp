@@ -30,6 +30,7 @@ struct ZScan {
 const ZScan kZ;
 
 inline int16_t sat16(int32_t v) { return (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+inline int16_t sat16(int16_t v) { return v; }
 inline int ilog2(int v) {
   int l = 0;
   while ((1 << l) < v) l++;
@@ -44,6 +45,7 @@ void PackedPicture::begin(const SeqInfo &s) {
   std::memset(rec4.data(), 0, rec4.size() * sizeof(Part4));
   for (int i = 0; i < 4; i++) tu[i].clear();
   coeff.clear();
+  coded_coeffs = 0;
   intra.clear();
   intra_nb.clear();
   ictu.clear();
@@ -179,8 +181,7 @@ void PackedPicture::walk_cu(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy,
     for (int comp = 0; comp < 3; comp++) {
       const int log2n = ilog2(size) - (comp ? 1 : 0), nn = 1 << (2 * log2n);
       const int16_t *src = ctu->pcm[comp] + (comp ? 4 * z : 16 * z);
-      const size_t off = coeff.size();
-      coeff.insert(coeff.end(), src, src + nn);
+      const uint32_t off = append_block(src, nn);
       TuItem t;
       std::memset(&t, 0, sizeof(t));
       t.x = (uint16_t)(comp ? x >> 1 : x);
@@ -188,7 +189,7 @@ void PackedPicture::walk_cu(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy,
       t.comp = (uint8_t)comp;
       t.flags = TU_PCM;
       t.qp = ctu->qp[z];
-      t.coeff_off = (uint32_t)off;
+      t.coeff_off = off;
       tu[log2n - 2].push_back(t);
     }
     return;
@@ -204,16 +205,31 @@ void PackedPicture::walk_cu(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy,
   }
 }
 
-// Appends one coded transform block: its work item and its coefficients (saturated to 16 bits, which
+// Appends the non-zero values of a block to the sparse coefficient stream (values saturated to 16 bits, which
 // loses nothing because de-quantisation clips its input to 16 bits first: TLibCommon/TComTrQuant.cpp:1181).
+// Returns the index of the block's header word.
+template <typename T> uint32_t PackedPicture::append_block(const T *src, int nn) {
+  const size_t off = coeff.size();
+  coeff.push_back(0);
+  uint32_t count = 0;
+  for (int i = 0; i < nn; i++) {
+    const int16_t v = sat16(src[i]);
+    if (v) {
+      coeff.push_back((uint32_t)i | ((uint32_t)(uint16_t)v << 16));
+      count++;
+    }
+  }
+  coeff[off] = count;
+  coded_coeffs += nn;
+  return (uint32_t)off;
+}
+
+// Appends one coded transform block: its work item and its coefficients.
 void PackedPicture::emit_tu(const hevcrecon_ctu_syntax *ctu, int comp, int z, int zcu, int x, int y, int log2n, int flags,
                             uint32_t *off_out) {
   const int n = 1 << log2n, nn = n * n;
   const int32_t *src = ctu->coeff[comp] + (comp ? 4 * z : 16 * z);
-  const size_t off = coeff.size();
-  coeff.resize(off + nn);
-  int16_t *dst = &coeff[off];
-  for (int i = 0; i < nn; i++) dst[i] = sat16(src[i]);
+  const uint32_t off = append_block(src, nn);
   TuItem t;
   std::memset(&t, 0, sizeof(t));
   t.x = (uint16_t)x;
@@ -222,9 +238,9 @@ void PackedPicture::emit_tu(const hevcrecon_ctu_syntax *ctu, int comp, int z, in
   t.flags = (uint8_t)(flags | (ctu->transform_skip[comp][z] ? TU_TSKIP : 0) |
                       ((ctu->transquant_bypass && ctu->transquant_bypass[z]) ? TU_BYPASS : 0));
   t.qp = ctu->qp[zcu];
-  t.coeff_off = (uint32_t)off;
+  t.coeff_off = off;
   tu[log2n - 2].push_back(t);
-  if (off_out) *off_out = (uint32_t)off;
+  if (off_out) *off_out = off;
 }
 
 void PackedPicture::inter_tus(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy, int zcu, int comp, int z, int size, int trdepth) {
@@ -523,7 +539,7 @@ int64_t PackedPicture::algorithmic_bytes() const {
   // one store of the reconstruction, read+write by deblocking, read+write by SAO when it is on
   int64_t total = sample_bytes * (1 + 2 + (sao ? 2 : 0));
   total += mc_ref_samples * by;  // luma and chroma have the same sample size in every supported profile
-  total += 2 * (int64_t)coeff.size();
+  total += 2 * coded_coeffs;
   total += 16 * (int64_t)seq.uw * seq.uh;
   return total;
 }

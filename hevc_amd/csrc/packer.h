@@ -14,7 +14,11 @@ struct PackedPicture {
   hevcrecon_pic_params pp;
   std::vector<Part4> rec4;
   std::vector<TuItem> tu[4];
-  std::vector<int16_t> coeff;
+  // Coded coefficients, sparse: per transform block one header word (number of non-zero coefficients) followed by
+  // that many words (position inside the block, raster) | (value << 16)
+  std::vector<uint32_t> coeff;
+  int64_t coded_coeffs;  // coefficients of all coded blocks, zeros included (the figure the algorithmic bytes use)
+  template <typename T> uint32_t append_block(const T *src, int nn);
   std::vector<IntraItem> intra;     // grouped by CTU, by local level inside a CTU
   std::vector<IntraCtu> ictu;       // CTUs holding intra blocks, sorted by wave after finish()
   std::vector<uint16_t> lvl_counts; // per CTU, per local level: number of blocks

@@ -166,7 +166,8 @@ int hevcrecon_syntax_create_detached(const hevcrecon_seq_params *sp, hevcrecon_s
  * [16..18] motion-compensation regions predicted as one block (64x64, 32x32, 16x16), [19] 16x16 regions predicted
  * unit by unit, [20..22] reference blocks read by the regions of [16..18] (one per list in use),
  * [23..25] luma samples those regions cover inside the picture, [26..28] the same weighted by lists in use,
- * [29] bytes copied to the device for this picture, [30] runs the 4x4 records were coded into. */
+ * [29] bytes copied to the device for this picture, [30] runs the 4x4 records were coded into,
+ * [31] bytes of the sparse coefficient stream. */
 int hevcrecon_syntax_stats(const hevcrecon_syntax *syn, int64_t out[32]);
 
 /* Start a new picture in `syn` (drops whatever it held).  Stands where TDecTop::xDecodeSlice
