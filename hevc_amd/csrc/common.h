@@ -24,7 +24,7 @@
 #include <stdint.h>
 
 #define HR_MAX_REFS 16
-#define HR_MAX_BATCH 64
+#define HR_MAX_BATCH 256
 
 // Part4.flags
 #define P4_DEPTH_MASK 0x03

@@ -589,7 +589,7 @@ extern "C" int64_t hevcrecon_syntax_algorithmic_bytes(const hevcrecon_syntax *s)
 // ---------------------------------------------------------------------------------------------
 extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, const int *dst_ids) {
   if (!c || !syn || !dst_ids) return 1;
-  if (n <= 0 || n > HR_MAX_BATCH) return fail(c, "batch size must be 1..64");
+  if (n <= 0 || n > HR_MAX_BATCH) return fail(c, "batch size must be 1..256");
   if (!c->have_seq) return fail(c, "no sequence parameters");
   HIPCHK(c, hipSetDevice(c->device));
   const SeqInfo &s = c->si;
