@@ -24,7 +24,7 @@ import re
 
 
 def short_name(k):
-    m = re.match(r"k_inter_tile<(\d+),", k)
+    m = re.match(r"k_inter_tile<(?:[^,]*, )?(\d+),", k)
     if m:
         return "k_inter_tile" + m.group(1)
     m = re.match(r"k_deblock<[^,]*, (\d)>", k)
