@@ -1009,6 +1009,82 @@ __device__ __forceinline__ int intra_ang_neg(const int *cn, int sgn, int inv, in
   return df ? (__mul24(32 - df, a0) + __mul24(df, a1) + 16) >> 5 : a0;
 }
 
+#define IT_WAVES 8 /* waves per workgroup (power of two) = blocks per round */
+#define IT_NTHR (IT_WAVES * 64)
+#define IT_YW 100 /* luma tile row: x = -1 .. 96 (97 used) */
+#define IT_CW 52  /* chroma tile row: x = -1 .. 48 (49 used) */
+// Prediction + residual + clip of the samples p_first, p_first + p_step, ... (raster inside the block) of one intra block,
+// written into the CTU tile (TLibCommon/TComPrediction.cpp:183-390,691-763).  w0 / w1: the block's first two item
+// words; refs: its reference samples (smoothed or not, as the block's mode asks).
+__device__ __forceinline__ void intra_predict(const SeqInfo &s, uint16_t *tile_y, uint16_t *tile_cb, uint16_t *tile_cr, const int16_t *resi_y,
+                                              const int16_t *resi_cb, const int16_t *resi_cr, int ctux, int ctuy, unsigned w0, unsigned w1,
+                                              const int *refs, int dcv, int p_first, int p_step) {
+    const int log2n = w1 & 255;
+    const int n = 1 << log2n, npx = n * n;
+    const int x0 = w0 & 0xffff, y0 = w0 >> 16;
+    const int comp = (w1 >> 8) & 255, mode = (w1 >> 16) & 255, flags = w1 >> 24;
+    const int sh = comp ? 1 : 0;
+    const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
+    uint16_t *tile = comp == 0 ? tile_y : comp == 1 ? tile_cb : tile_cr;
+    const int tw = comp ? IT_CW : IT_YW;
+    const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
+    const int *cn = refs + 2 * n;  // cn[0] corner, cn[-1-j] left[j], cn[1+i] above[i]
+    const bool edge = comp == 0 && n <= 16;
+    const int16_t *resi = comp == 0 ? resi_y : comp == 1 ? resi_cb : resi_cr;
+    const int rw = comp ? 32 : 64;
+    const bool has_resi = (flags & IN_HAS_RESI) != 0;
+    const int16_t *resi0 = resi + (ty0 - 1) * rw + tx0 - 1;
+    uint16_t *tile0 = tile + ty0 * tw + tx0;
+#define INTRA_STORE_LOOP(EXPR)                                       \
+  for (int p = p_first; p < npx; p += p_step) {                      \
+const int py = p >> log2n, px = p & (n - 1);                     \
+int v = (EXPR);                                                  \
+if (has_resi) v += resi0[py * rw + px];                          \
+tile0[py * tw + px] = (uint16_t)clip3i(0, maxv, v);              \
+  }
+    if (mode == 0) {  // planar
+      const int tr = cn[1 + n], bl = cn[-1 - n];
+      INTRA_STORE_LOOP(((cn[-1 - py] << log2n) + n + __mul24(px + 1, tr - cn[-1 - py]) + (cn[1 + px] << log2n) + __mul24(py + 1, bl - cn[1 + px])) >> (log2n + 1))
+    } else if (mode == 1) {  // DC
+      if (edge) {
+        INTRA_STORE_LOOP((px == 0 && py == 0) ? (cn[1] + cn[-1] + 2 * dcv + 2) >> 2
+                         : py == 0            ? (cn[1 + px] + 3 * dcv + 2) >> 2
+                         : px == 0            ? (cn[-1 - py] + 3 * dcv + 2) >> 2
+                                              : dcv)
+      } else {
+        INTRA_STORE_LOOP(dcv)
+      }
+    } else {
+      // angular: vertical modes predict from the row above, horizontal modes are the same computation
+      // on the transposed block (main = left column): sgn flips the index direction
+      const bool hor = mode < 18;
+      const int a = hor ? -(mode - 10) : mode - 26;
+      const int aa = iabs(a);
+      const int at = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
+      const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
+      const int angle = a < 0 ? -at : at;
+      const int sgn = hor ? -1 : 1;  // MAIN(i) = cn[sgn * i], SIDE(i) = cn[-sgn * i]
+#define KK (hor ? px : py) /* index along the prediction direction */
+#define EE (hor ? py : px) /* index across it */
+      if (angle == 0) {
+        if (edge) {
+          const int side0 = cn[0];
+          INTRA_STORE_LOOP(EE == 0 ? clip3i(0, maxv, cn[sgn] + ((cn[-sgn * (KK + 1)] - side0) >> 1)) : cn[sgn * (EE + 1)])
+        } else {
+          INTRA_STORE_LOOP(cn[sgn * (EE + 1)])
+        }
+      } else if (angle > 0) {
+        INTRA_STORE_LOOP(intra_ang_pos(cn, sgn, EE + 1 + (__mul24(KK + 1, angle) >> 5), __mul24(KK + 1, angle) & 31))
+      } else {
+        // negative indices address the side reference projected onto the main one
+        INTRA_STORE_LOOP(intra_ang_neg(cn, sgn, inv, EE + 1 + (__mul24(KK + 1, angle) >> 5), __mul24(KK + 1, angle) & 31))
+      }
+#undef KK
+#undef EE
+    }
+#undef INTRA_STORE_LOOP
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_intra: intra prediction + residual add.  One workgroup per CTU, one launch per CTU wave.
 // ------------------------------------------------------------------------------------------------
@@ -1022,10 +1098,6 @@ __device__ __forceinline__ int intra_ang_neg(const int *cn, int sgn, int inv, in
 // Reference-sample array r[0..4n]: r[2n] is the corner, r[2n-1-j] the left column going down,
 // r[2n+1+i] the row above going right (TComPattern::initAdiPattern / fillReferenceSamples,
 // TLibCommon/TComPattern.cpp:213-602).  Availability comes per 4-luma-sample unit from the packer.
-#define IT_WAVES 8 /* waves per workgroup (power of two) = blocks per round */
-#define IT_NTHR (IT_WAVES * 64)
-#define IT_YW 100 /* luma tile row: x = -1 .. 96 (97 used) */
-#define IT_CW 52  /* chroma tile row: x = -1 .. 48 (49 used) */
 #define IT_MAX_ITEMS HR_INTRA_MAX_ITEMS
 #define IT_MAX_LEVELS HR_INTRA_MAX_LEVELS
 
@@ -1139,6 +1211,12 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
     const int cnt = hr_uniform((int)lvlc_s[lvl]);
     for (int r0 = 0; r0 < cnt; r0 += IT_WAVES) {
       const int nb = min(IT_WAVES, cnt - r0);  // blocks of this round
+      // A round without a 32x32 block is finished by the waves that build the references: each predicts its own
+      // block (at most four passes of 64 samples) and the round costs one barrier.  The 16 passes of a 32x32 block
+      // are worth spreading over all waves, at the price of a hand-over through LDS and a second barrier.
+      unsigned round_log2n = 0;
+      if (lane < nb && base + r0 + lane < IT_MAX_ITEMS) round_log2n = ((const unsigned *)&items_s[base + r0 + lane])[1] & 255;
+      const bool two_phase = __ballot(round_log2n == 5) != 0;
       // ---- phase A: wave b builds the reference samples of block b ----
       if (wv < nb) {
         int *ref = ref_s[wv], *flt = flt_s[wv];
@@ -1261,13 +1339,20 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
           for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
           dcv = (part + n) >> (log2n + 1);
         }
-        if (lane == 0) {
-          blk_s[wv][0] = w0;
-          blk_s[wv][1] = in_range ? w1 : 0u;  // log2n = 0 marks a slot without a block
-          blk_s[wv][2] = use_flt ? 1u : 0u;
-          blk_s[wv][3] = (unsigned)dcv;
+        if (two_phase) {
+          if (lane == 0) {
+            blk_s[wv][0] = w0;
+            blk_s[wv][1] = in_range ? w1 : 0u;  // log2n = 0 marks a slot without a block
+            blk_s[wv][2] = use_flt ? 1u : 0u;
+            blk_s[wv][3] = (unsigned)dcv;
+          }
+        } else {
+          hr_wave_sync();  // the smoothed samples were written by other lanes of this wave
+          if (in_range)
+            intra_predict(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, use_flt ? flt : ref, dcv, lane, 64);
         }
       }
+      if (two_phase) {
       __syncthreads();
       // ---- phase B: prediction + residual + store (TLibCommon/TComPrediction.cpp:183-390,691-763), all waves
       //      over all blocks of the round, 64 samples at a time
@@ -1291,73 +1376,12 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
         const int b = __ffsll((long long)mine) - 1;
         mine &= mine - 1;
         const unsigned w0 = (unsigned)hr_readlane((int)my0, b), w1 = (unsigned)hr_readlane((int)my1, b);
-        const int log2n = w1 & 255;
-        const int n = 1 << log2n, npx = n * n;
         const int c0 = (wv - hr_readlane(my_chunk0, b)) & (IT_WAVES - 1);
         const bool use_flt = hr_readlane((int)my2, b) != 0;
         const int dcv = hr_readlane((int)my3, b);
-        const int x0 = w0 & 0xffff, y0 = w0 >> 16;
-        const int comp = (w1 >> 8) & 255, mode = (w1 >> 16) & 255, flags = w1 >> 24;
-        const int sh = comp ? 1 : 0;
-        const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
-        uint16_t *tile = comp ? tile_c[comp - 1] : tile_y;
-        const int tw = comp ? IT_CW : IT_YW;
-        const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
-        const int *cn = (use_flt ? flt_s[b] : ref_s[b]) + 2 * n;  // cn[0] corner, cn[-1-j] left[j], cn[1+i] above[i]
-        const bool edge = comp == 0 && n <= 16;
-        const int16_t *resi = comp ? resi_c[comp - 1] : resi_y;
-        const int rw = comp ? 32 : 64;
-        const bool has_resi = (flags & IN_HAS_RESI) != 0;
-        const int16_t *resi0 = resi + (ty0 - 1) * rw + tx0 - 1;
-        uint16_t *tile0 = tile + ty0 * tw + tx0;
-#define INTRA_STORE_LOOP(EXPR)                                       \
-  for (int p = c0 * 64 + lane; p < npx; p += IT_WAVES * 64) {        \
-    const int py = p >> log2n, px = p & (n - 1);                     \
-    int v = (EXPR);                                                  \
-    if (has_resi) v += resi0[py * rw + px];                          \
-    tile0[py * tw + px] = (uint16_t)clip3i(0, maxv, v);              \
-  }
-        if (mode == 0) {  // planar
-          const int tr = cn[1 + n], bl = cn[-1 - n];
-          INTRA_STORE_LOOP(((cn[-1 - py] << log2n) + n + __mul24(px + 1, tr - cn[-1 - py]) + (cn[1 + px] << log2n) + __mul24(py + 1, bl - cn[1 + px])) >> (log2n + 1))
-        } else if (mode == 1) {  // DC
-          if (edge) {
-            INTRA_STORE_LOOP((px == 0 && py == 0) ? (cn[1] + cn[-1] + 2 * dcv + 2) >> 2
-                             : py == 0            ? (cn[1 + px] + 3 * dcv + 2) >> 2
-                             : px == 0            ? (cn[-1 - py] + 3 * dcv + 2) >> 2
-                                                  : dcv)
-          } else {
-            INTRA_STORE_LOOP(dcv)
-          }
-        } else {
-          // angular: vertical modes predict from the row above, horizontal modes are the same computation
-          // on the transposed block (main = left column): sgn flips the index direction
-          const bool hor = mode < 18;
-          const int a = hor ? -(mode - 10) : mode - 26;
-          const int aa = iabs(a);
-          const int at = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
-          const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
-          const int angle = a < 0 ? -at : at;
-          const int sgn = hor ? -1 : 1;  // MAIN(i) = cn[sgn * i], SIDE(i) = cn[-sgn * i]
-#define KK (hor ? px : py) /* index along the prediction direction */
-#define EE (hor ? py : px) /* index across it */
-          if (angle == 0) {
-            if (edge) {
-              const int side0 = cn[0];
-              INTRA_STORE_LOOP(EE == 0 ? clip3i(0, maxv, cn[sgn] + ((cn[-sgn * (KK + 1)] - side0) >> 1)) : cn[sgn * (EE + 1)])
-            } else {
-              INTRA_STORE_LOOP(cn[sgn * (EE + 1)])
-            }
-          } else if (angle > 0) {
-            INTRA_STORE_LOOP(intra_ang_pos(cn, sgn, EE + 1 + (__mul24(KK + 1, angle) >> 5), __mul24(KK + 1, angle) & 31))
-          } else {
-            // negative indices address the side reference projected onto the main one
-            INTRA_STORE_LOOP(intra_ang_neg(cn, sgn, inv, EE + 1 + (__mul24(KK + 1, angle) >> 5), __mul24(KK + 1, angle) & 31))
-          }
-#undef KK
-#undef EE
-        }
-#undef INTRA_STORE_LOOP
+        intra_predict(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, (use_flt ? flt_s[b] : ref_s[b]), dcv,
+                      c0 * 64 + lane, IT_WAVES * 64);
+      }
       }
       __syncthreads();  // the next round reads what this one wrote into the tile and reuses the block slots
     }
