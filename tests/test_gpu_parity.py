@@ -81,6 +81,32 @@ def test_errors_are_reported_not_crashed():
     eng.close()
 
 
+def test_packed_pictures_can_be_uploaded_again():
+    """hevcrecon_syntax_upload: a packed picture copied to the device a second time (runs expanded again, while
+    other pictures are being reconstructed) gives the same picture; an unfinished one is refused."""
+    seq = load_golden("randomaccess_main_416x240")
+    bd = bit_depths(seq)
+    eng = engine.Engine(seq.seq_params)
+    syns = []
+    for pic in seq.pictures:
+        syns.append(eng.new_syntax().pack(pic))
+        eng.reconstruct(syns[-1], pic.pic_id)
+    for pic, syn in zip(seq.pictures, syns):
+        syn.upload()
+    for pic, syn in zip(seq.pictures, syns):
+        syn.upload()  # twice in a row, with the first copy possibly still in flight
+        eng.reconstruct(syn, pic.pic_id)
+        final = eng.download(pic.pic_id)
+        assert [syntax.plane_md5(final[c], bd[c]) for c in range(3)] == pic.stage_md5[2], pic.poc
+    fresh = eng.new_syntax()
+    with pytest.raises(engine.EngineError):
+        fresh.upload()
+    fresh.close()
+    for s in syns:
+        s.close()
+    eng.close()
+
+
 @pytest.mark.parametrize("stream", ["randomaccess_main", "randomaccess_he10", "intra_main"])
 def test_all_stages_md5_exact_1080p(stream):
     """BASELINE configs 2-4 at full size: every picture's three stages against the MD5s of the reference

@@ -78,3 +78,52 @@ def test_bad_sequence_parameters_are_rejected():
     assert lib.hevcrecon_syntax_create_detached(C.byref(sp), C.byref(h)) != 0
     sp = abi.SeqParams(width=417, height=240, bit_depth_luma=8, bit_depth_chroma=8, ctu_size=64, max_cu_depth=4)
     assert lib.hevcrecon_syntax_create_detached(C.byref(sp), C.byref(h)) != 0
+
+
+def test_hand_over_is_compact():
+    """The 4x4 records travel run-length coded and the coefficients sparse: far fewer runs than records, and the
+    sparse stream never holds more words than one per coded coefficient plus one per block."""
+    seq = load_golden("randomaccess_main_416x240")
+    syn = engine.detached_syntax(seq.seq_params)
+    for pic in seq.pictures:
+        syn.pack(pic)
+        st = syn.stats()
+        nctu = pic.nctu
+        assert nctu <= st[30] <= st[8]           # at least one run per CTU, at most one per record
+        assert st[30] * 4 < st[8]                # and a real saving on this stream
+        blocks = st[0] + st[1] + st[2] + st[3]
+        nonzero = sum(int(np.count_nonzero(pic.a["coeff%d" % c])) for c in range(3))
+        assert 4 * blocks <= st[31] <= 4 * (blocks + min(st[4], nonzero))
+    syn.close()
+
+
+def test_prediction_weights_are_range_checked():
+    seq = load_golden("wpp_416x240", 2)
+    lib = abi.load_library()
+    syn = engine.detached_syntax(seq.seq_params)
+    assert lib.hevcrecon_syntax_begin(syn.h) == 0
+    w = abi.PredWeights.from_buffer_copy(bytes(seq.pictures[1].pred_weights))
+    assert lib.hevcrecon_syntax_set_pred_weights(syn.h, C.addressof(w)) == 0
+    w.log2_denom[0][0][0] = 8
+    assert lib.hevcrecon_syntax_set_pred_weights(syn.h, C.addressof(w)) != 0
+    w.log2_denom[0][0][0] = 6
+    w.weight[1][3][2] = 300
+    assert lib.hevcrecon_syntax_set_pred_weights(syn.h, C.addressof(w)) != 0
+    assert lib.hevcrecon_syntax_set_pred_weights(syn.h, None) == 0
+    syn.close()
+
+
+def test_ipcm_unit_without_samples_is_refused():
+    seq = load_golden("pcmlf_416x240", 1)
+    pic = seq.pictures[0]
+    lib = abi.load_library()
+    syn = engine.detached_syntax(seq.seq_params)
+    ctus = pic.ctu_structs()
+    a = sorted(pic.pcm)[0]  # a CTU that holds IPCM units
+    assert lib.hevcrecon_syntax_begin(syn.h) == 0
+    for i in range(a):
+        assert lib.hevcrecon_syntax_add_ctu(syn.h, i, C.byref(ctus[i])) == 0
+    broken = abi.CtuSyntax.from_buffer_copy(bytes(ctus[a]))
+    broken.pcm[0] = None
+    assert lib.hevcrecon_syntax_add_ctu(syn.h, a, C.byref(broken)) != 0
+    syn.close()
