@@ -80,10 +80,30 @@ constexpr T32Table make_t32() {
     }
   return t;
 }
-__constant__ T32Table kT32tab = make_t32();
-#define kT32 kT32tab.v
-// 4-point inverse DST used for intra luma 4x4 (TLibCommon/TComRom.cpp:316-322).
-__constant__ int8_t kDst4[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
+// The same matrices as 16-bit pairs for the 2-way dot product: entry [log2 N - 2][k / 2][i] holds rows k and k + 1
+// of the N-point matrix at column i.
+struct TPairTable {
+  unsigned v[4][16][32];
+};
+constexpr TPairTable make_tpairs() {
+  const T32Table t = make_t32();
+  TPairTable p = {};
+  for (int l = 0; l < 4; l++) {
+    const int n = 4 << l, r = 32 / n;
+    for (int kp = 0; kp < n / 2; kp++)
+      for (int i = 0; i < n; i++) {
+        const int lo = t.v[2 * kp * r][i], hi = t.v[(2 * kp + 1) * r][i];
+        p.v[l][kp][i] = ((unsigned)lo & 0xffffu) | (((unsigned)hi & 0xffffu) << 16);
+      }
+  }
+  return p;
+}
+__constant__ TPairTable kTPtab = make_tpairs();
+#define kTP kTPtab.v
+// 4-point inverse DST used for intra luma 4x4 (TLibCommon/TComRom.cpp:316-322), rows (0,1) and (2,3) paired likewise.
+#define HR_P16(a, b) (((unsigned)(a)&0xffffu) | (((unsigned)(b)&0xffffu) << 16))
+__constant__ unsigned kDst4P[2][4] = {{HR_P16(29, 74), HR_P16(55, 74), HR_P16(74, 0), HR_P16(84, -74)},
+                                      {HR_P16(84, 55), HR_P16(-29, -84), HR_P16(-74, 74), HR_P16(55, -29)}};
 // chroma QP mapping (TLibCommon/TComRom.cpp:306-312)
 __constant__ uint8_t kChromaScale[58] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
                                          20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 33, 33, 34, 34, 35, 35,
@@ -916,29 +936,37 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
   }
   const int sl_shift = shift + 4 - per;  // > 0: round and shift right; <= 0: shift left
   const int sl_lim = 1 << min(15, 12 + LOG2N + bd - per);
+  // Rows are taken two at a time: both factors fit 16 bits (the de-quantised value is clipped to 16 bits, the
+  // matrix entries to 8), so one 2-way 16-bit dot product does two multiply-adds exactly.
 #pragma unroll
-  for (int k = 0; k < N; k++) {
-    int d;
-    if (!sl) {
-      d = clip3i(-32768, 32767, (dq[k] * scale + add) >> shift);
-    } else {
-      constexpr int RATIO = N / (N < 8 ? N : 8);
-      const int mk = (RATIO > 1 && k == 0 && c == 0) ? mdc : mrow[k / RATIO];
-      const int coef = iq * mk;
-      if (sl_shift > 0)
-        d = clip3i(-32768, 32767, (dq[k] * coef + (1 << (sl_shift - 1))) >> sl_shift);
-      else
-        d = clip3i(-32768, 32767, (clip3i(-sl_lim, sl_lim - 1, dq[k]) * coef) << (-sl_shift));
+  for (int k2 = 0; k2 < N; k2 += 2) {
+    int dd[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int k = k2 + h;
+      int d;
+      if (!sl) {
+        d = clip3i(-32768, 32767, (dq[k] * scale + add) >> shift);
+      } else {
+        constexpr int RATIO = N / (N < 8 ? N : 8);
+        const int mk = (RATIO > 1 && k == 0 && c == 0) ? mdc : mrow[k / RATIO];
+        const int coef = iq * mk;
+        if (sl_shift > 0)
+          d = clip3i(-32768, 32767, (dq[k] * coef + (1 << (sl_shift - 1))) >> sl_shift);
+        else
+          d = clip3i(-32768, 32767, (clip3i(-sl_lim, sl_lim - 1, dq[k]) * coef) << (-sl_shift));
+      }
+      if (tskip) tmp[t_local][k][c] = d;  // transform-skip blocks bypass both passes: keep the de-quantised block as it is
+      if (bypass) tmp[t_local][k][c] = dq[k];
+      dd[h] = (tskip || bypass) ? 0 : d;
     }
-    if (tskip) tmp[t_local][k][c] = d;  // transform-skip blocks bypass both passes: keep the de-quantised block as it is
-    if (bypass) tmp[t_local][k][c] = dq[k];
-    const int dd = (tskip || bypass) ? 0 : d;
-    if (!__any(dd != 0)) continue;  // wave-uniform
+    if (!__any((dd[0] | dd[1]) != 0)) continue;  // wave-uniform
+    const unsigned pk = pack16(dd[0], dd[1]);
 #pragma unroll
     for (int y = 0; y < N; y++) {
-      const int m = kT32[k * (32 / N)][y];
-      const int md = (LOG2N == 2) ? kDst4[k][y & 3] : 0;
-      acc[y] += __mul24(dst4 ? md : m, dd);  // 8-bit x 16-bit: the 24-bit multiplier is exact and runs at full rate
+      const unsigned m = kTP[LOG2N - 2][k2 / 2][y];
+      const unsigned md = (LOG2N == 2) ? kDst4P[k2 / 2][y & 3] : 0u;
+      acc[y] = hr_sdot2(pk, dst4 ? md : m, acc[y]);
     }
   }
   if (!tskip && !bypass) {
@@ -955,14 +983,15 @@ __global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s
 #pragma unroll
   for (int k = 0; k < N; k++) row[k] = tmp[t_local][y][k];
 #pragma unroll
-  for (int k = 0; k < N; k++) {
-    const int v = (tskip || bypass) ? 0 : row[k];
-    if (!__any(v != 0)) continue;  // wave-uniform
+  for (int k2 = 0; k2 < N; k2 += 2) {
+    const int v0 = (tskip || bypass) ? 0 : row[k2], v1 = (tskip || bypass) ? 0 : row[k2 + 1];
+    if (!__any((v0 | v1) != 0)) continue;  // wave-uniform
+    const unsigned pk = pack16(v0, v1);
 #pragma unroll
     for (int x = 0; x < N; x++) {
-      const int m = kT32[k * (32 / N)][x];
-      const int md = (LOG2N == 2) ? kDst4[k][x & 3] : 0;
-      res[x] += __mul24(dst4 ? md : m, v);
+      const unsigned m = kTP[LOG2N - 2][k2 / 2][x];
+      const unsigned md = (LOG2N == 2) ? kDst4P[k2 / 2][x & 3] : 0u;
+      res[x] = hr_sdot2(pk, dst4 ? md : m, res[x]);
     }
   }
   if (bypass) {
