@@ -98,7 +98,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=64, help="independent streams per GPU")
+    ap.add_argument("--streams", type=int, default=128,
+                    help="independent streams per GPU; larger batches amortise the latency-bound intra launches "
+                         "(measured: 64 -> 72.9 k, 128 -> 81.6 k, 256 -> 86.4 k frames/s)")
     ap.add_argument("--contexts", type=int, default=1, help="engine contexts (HIP streams) the streams of this GPU are spread over")
     ap.add_argument("--fixture", default="randomaccess_main_1920x1080")
     ap.add_argument("--no-cpu-baseline", action="store_true")
