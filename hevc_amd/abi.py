@@ -116,6 +116,7 @@ EXPORTS = {
     "hevcrecon_syntax_add_ctu": (C.c_int, [_P, C.c_int, C.POINTER(CtuSyntax)]),
     "hevcrecon_syntax_finish": (C.c_int, [_P, C.POINTER(PicParams)]),
     "hevcrecon_syntax_upload": (C.c_int, [_P]),
+    "hevcrecon_syntax_upload_batch": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "hevcrecon_reconstruct": (C.c_int, [_P, _P, C.c_int]),
     "hevcrecon_reconstruct_batch": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int)]),
     "hevcrecon_picture_download": (C.c_int, [_P, C.c_int, _I16P, _I16P, _I16P, C.c_int, C.c_int]),

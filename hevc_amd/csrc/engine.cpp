@@ -23,6 +23,12 @@
 namespace {
 const int kMaxPics = 1 << 16;
 const int kRing = 16;
+// Copy streams.  A copy command costs the copy engine ~10 us whatever its size; pictures are ~0.2 MB, so one stream
+// would spend most of its time on that.  Copies of a batch go round-robin over several streams: three, which with
+// the kernels' stream makes the four hardware queues a process gets (measured with-upload rate of the benchmark:
+// 1 stream 53 k, 3 streams 64 k, 4 streams 65 k, 8 streams 44 k frames/s; a kernel reading the pinned buffers
+// itself reached only 10 GB/s over the link).
+const int kCopyStreams = 3;
 
 struct DevPicture {
   void *base = nullptr;
@@ -40,7 +46,8 @@ struct Interval {
 struct hevcrecon_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;  // syntax uploads (+ their expansion) run beside the reconstruction kernels
+  hipStream_t copy_stream[kCopyStreams] = {};  // syntax uploads run beside the reconstruction kernels
+  int copy_rr = 0;
   bool have_seq = false;
   hevcrecon_seq_params sp;
   SeqInfo si;
@@ -63,7 +70,7 @@ struct hevcrecon_ctx {
   // Cross-stream waits are expensive, and both streams run in order: the main stream waits for an upload only
   // when it is newer than the newest one it has already waited for, and the copy stream likewise for batches.
   int64_t upload_no = 0, upload_waited = -1, upload_synced = -1, batch_waited = -1;
-  hipEvent_t copy_ev[kRing];  // recorded on the copy stream when the main stream has to wait for uploads
+  hipEvent_t copy_ev[kRing * kCopyStreams];  // recorded on the copy streams when the main stream has to wait for uploads
   int copy_ev_pos = 0;
   int ring_pos = 0;
   int32_t *error_flag_dev = nullptr;
@@ -84,6 +91,7 @@ struct hevcrecon_syntax {
   char *dev = nullptr;
   size_t dev_cap = 0;
   char *host = nullptr;  // pinned staging
+  bool dirty = false;    // the staging buffer holds a picture the device copy does not have yet
   size_t host_cap = 0;
   size_t upload_bytes = 0, off_runs = 0, off_runoff = 0;
   bool expanded = false;       // rec4 has been expanded from the uploaded runs
@@ -263,13 +271,14 @@ extern "C" int hevcrecon_create(hevcrecon_ctx **out, int device) {
   std::memset(c->launches, 0, sizeof(c->launches));
   std::memset(c->ring_used, 0, sizeof(c->ring_used));
   bool ok = hipStreamCreate(&c->stream) == hipSuccess;
-  ok = ok && hipStreamCreate(&c->copy_stream) == hipSuccess;
+  for (int i = 0; ok && i < kCopyStreams; i++) ok = hipStreamCreate(&c->copy_stream[i]) == hipSuccess;
   ok = ok && hipHostMalloc((void **)&c->jobs_host, sizeof(PicJob) * HR_MAX_BATCH * kRing) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->jobs_dev, sizeof(PicJob) * HR_MAX_BATCH * kRing) == hipSuccess;
+
   ok = ok && hipMalloc((void **)&c->error_flag_dev, 64) == hipSuccess;
   for (int i = 0; ok && i < kRing; i++) ok = hipEventCreate(&c->ring_ev[i]) == hipSuccess;
   for (int i = 0; ok && i < kRing; i++) ok = hipEventCreateWithFlags(&c->batch_ev[i], hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; ok && i < kRing; i++) ok = hipEventCreateWithFlags(&c->copy_ev[i], hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; ok && i < kRing * kCopyStreams; i++) ok = hipEventCreateWithFlags(&c->copy_ev[i], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     delete c;
     return 3;
@@ -295,13 +304,15 @@ extern "C" void hevcrecon_destroy(hevcrecon_ctx *c) {
   for (size_t i = 0; i < c->event_pool.size(); i++) hipEventDestroy(c->event_pool[i]);
   for (int i = 0; i < kRing; i++) hipEventDestroy(c->ring_ev[i]);
   for (int i = 0; i < kRing; i++) hipEventDestroy(c->batch_ev[i]);
-  for (int i = 0; i < kRing; i++) hipEventDestroy(c->copy_ev[i]);
+  for (int i = 0; i < kRing * kCopyStreams; i++) hipEventDestroy(c->copy_ev[i]);
   if (c->jobs_host) hipHostFree(c->jobs_host);
   if (c->jobs_dev) hipFree(c->jobs_dev);
+
   if (c->error_flag_dev) hipFree(c->error_flag_dev);
   if (c->dl_host) hipHostFree(c->dl_host);
   hipStreamDestroy(c->stream);
-  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+  for (int i = 0; i < kCopyStreams; i++)
+    if (c->copy_stream[i]) hipStreamDestroy(c->copy_stream[i]);
   delete c;
 }
 
@@ -369,7 +380,7 @@ extern "C" void hevcrecon_syntax_destroy(hevcrecon_syntax *s) {
   if (!s) return;
   if (s->ctx) {
     hipSetDevice(s->ctx->device);
-    hipStreamSynchronize(s->ctx->copy_stream);
+    for (int k = 0; k < kCopyStreams; k++) hipStreamSynchronize(s->ctx->copy_stream[k]);
     hipStreamSynchronize(s->ctx->stream);
   }
   if (s->dev) hipFree(s->dev);
@@ -386,7 +397,7 @@ extern "C" int hevcrecon_syntax_begin(hevcrecon_syntax *s) {
     // device copy must be done, before either is rewritten
     if (s->uploaded) {
       if (s->upload_seq > s->ctx->upload_synced) {
-        hipStreamSynchronize(s->ctx->copy_stream);
+        for (int k = 0; k < kCopyStreams; k++) hipStreamSynchronize(s->ctx->copy_stream[k]);
         s->ctx->upload_synced = s->ctx->upload_no - 1;
       }
       if (s->last_batch >= 0) hipEventSynchronize(s->ctx->batch_ev[s->last_batch % kRing]);
@@ -435,12 +446,12 @@ extern "C" int hevcrecon_syntax_add_ctu(hevcrecon_syntax *s, int ctu_addr, const
   return 0;
 }
 
-// Copy of the packed picture to the device, on the copy stream (nothing but copies runs there, so uploads never
-// queue behind kernels).  The run-length coded motion records are expanded by the first batch that uses them.
+// The packed picture is ready in its pinned staging buffer.  It crosses the host link when the first batch that
+// uses it is submitted: the copies of all pictures of the batch that need one go out together, spread over the copy
+// streams (beside the previous batch's kernels, which the host has queued ahead), then k_expand expands the
+// run-length coded records.
 static int queue_upload(hevcrecon_syntax *s) {
-  hevcrecon_ctx *c = s->ctx;
-  HIPCHK(c, hipMemcpyAsync(s->dev, s->host, s->upload_bytes, hipMemcpyHostToDevice, c->copy_stream));
-  s->upload_seq = c->upload_no++;
+  s->dirty = true;
   s->uploaded = true;
   s->expanded = false;
   return 0;
@@ -480,7 +491,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   s->off_rec4 = place(k.rec4.size() * sizeof(Part4));  // device only: expanded from the runs after the copy
   const size_t total = off;
   if (s->dev_cap < total) {
-    HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+    for (int k = 0; k < kCopyStreams; k++) HIPCHK(c, hipStreamSynchronize(c->copy_stream[k]));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (s->dev) hipFree(s->dev);
     s->dev = nullptr;
@@ -513,18 +524,19 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   return queue_upload(s);
 }
 
-// No counterpart in the reference: queues the host-to-device copy of an already packed picture again
+// No counterpart in the reference: marks an already packed picture for another trip to the device
 // (hevcrecon_syntax_finish does it once).  For hosts that keep packed pictures and for measuring the hand-over.
 extern "C" int hevcrecon_syntax_upload(hevcrecon_syntax *s) {
   if (!s) return 1;
   if (!s->ctx || !s->pk.finished || !s->dev) return fail(s->ctx, "nothing to upload: the picture is not finished on a context");
-  HIPCHK(s->ctx, hipSetDevice(s->ctx->device));
-  // kernels already queued may still read the device copy that is about to be rewritten
-  if (s->last_batch > s->ctx->batch_waited) {
-    HIPCHK(s->ctx, hipStreamWaitEvent(s->ctx->copy_stream, s->ctx->batch_ev[s->last_batch % kRing], 0));
-    s->ctx->batch_waited = s->last_batch;
-  }
   return queue_upload(s);
+}
+
+extern "C" int hevcrecon_syntax_upload_batch(int n, hevcrecon_syntax *const *syn) {
+  if (n < 0 || (n > 0 && !syn)) return 1;
+  for (int i = 0; i < n; i++)
+    if (int rc = hevcrecon_syntax_upload(syn[i])) return rc;
+  return 0;
 }
 
 extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[32]) {
@@ -701,14 +713,40 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     j.error_flag = c->error_flag_dev;
     any_deblock = any_deblock || !k.pp.deblocking_disable;
   }
-  {  // device copies complete: one event behind everything the copy stream holds covers the whole batch
+  {  // hand-over of the pictures whose device copy is stale
+    int64_t newest_reader = -1;
+    bool any = false;
+    for (int i = 0; i < n; i++)
+      if (syn[i]->dirty) {
+        any = true;
+        newest_reader = std::max(newest_reader, syn[i]->last_batch);
+      }
+    if (any) {
+      // kernels already queued may still read a device copy that is about to be rewritten
+      if (newest_reader > c->batch_waited) {
+        for (int k = 0; k < kCopyStreams; k++) HIPCHK(c, hipStreamWaitEvent(c->copy_stream[k], c->batch_ev[newest_reader % kRing], 0));
+        c->batch_waited = newest_reader;
+      }
+      for (int i = 0; i < n; i++) {
+        hevcrecon_syntax *y = syn[i];
+        if (!y->dirty) continue;
+        HIPCHK(c, hipMemcpyAsync(y->dev, y->host, y->upload_bytes, hipMemcpyHostToDevice, c->copy_stream[c->copy_rr]));
+        c->copy_rr = (c->copy_rr + 1) % kCopyStreams;
+        y->dirty = false;
+        y->upload_seq = c->upload_no;
+      }
+      c->upload_no++;
+    }
+    // device copies complete: events behind everything the copy streams hold cover the whole batch
     bool wait = false;
     for (int i = 0; i < n; i++) wait = wait || syn[i]->upload_seq > c->upload_waited;
     if (wait) {
-      hipEvent_t e = c->copy_ev[c->copy_ev_pos];
+      for (int k = 0; k < kCopyStreams; k++) {
+        hipEvent_t e = c->copy_ev[c->copy_ev_pos * kCopyStreams + k];
+        HIPCHK(c, hipEventRecord(e, c->copy_stream[k]));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
+      }
       c->copy_ev_pos = (c->copy_ev_pos + 1) % kRing;
-      HIPCHK(c, hipEventRecord(e, c->copy_stream));
-      HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
       c->upload_waited = c->upload_no - 1;
     }
   }
@@ -866,7 +904,7 @@ extern "C" int hevcrecon_picture_release(hevcrecon_ctx *c, int pic_id) {
 extern "C" int hevcrecon_synchronize(hevcrecon_ctx *c) {
   if (!c) return 1;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipStreamSynchronize(c->copy_stream));
+  for (int k = 0; k < kCopyStreams; k++) HIPCHK(c, hipStreamSynchronize(c->copy_stream[k]));
   c->upload_synced = c->upload_no - 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;

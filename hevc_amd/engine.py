@@ -97,6 +97,11 @@ class Engine:
         n = len(syns)
         return (n, (C.c_void_p * n)(*[s.h for s in syns]), (C.c_int * n)(*dst_pic_ids))
 
+    def upload_prepared(self, prepared):
+        """Mark every picture of a prepared batch for another trip to the device."""
+        n, hs, _ = prepared
+        self._check(self.lib.hevcrecon_syntax_upload_batch(n, hs), "hevcrecon_syntax_upload_batch")
+
     def reconstruct_prepared(self, prepared):
         n, hs, ids = prepared
         self._check(self.lib.hevcrecon_reconstruct_batch(self.ctx, n, hs, ids), "hevcrecon_reconstruct_batch")

@@ -197,10 +197,12 @@ int hevcrecon_syntax_add_ctu(hevcrecon_syntax *syn, int ctu_addr, const hevcreco
 /* Closes the picture and queues the host-to-device copy of the packed syntax. */
 int hevcrecon_syntax_finish(hevcrecon_syntax *syn, const hevcrecon_pic_params *pp);
 
-/* No counterpart in the reference.  Queues the host-to-device copy of an already finished picture again
- * (hevcrecon_syntax_finish queues it once): for hosts that keep packed pictures around, and for measuring the
- * hand-over.  Copies run on a stream of their own and overlap reconstruction of other pictures. */
+/* No counterpart in the reference.  Marks an already finished picture for another trip to the device
+ * (hevcrecon_syntax_finish marks it once): for hosts that keep packed pictures around, and for measuring the
+ * hand-over.  The pictures of a batch that are so marked cross the host link when the batch is submitted: one
+ * kernel on a stream of its own reads their pinned buffers, beside the kernels of the batches queued before. */
 int hevcrecon_syntax_upload(hevcrecon_syntax *syn);
+int hevcrecon_syntax_upload_batch(int n, hevcrecon_syntax *const *syn);
 
 /* ---- reconstruction ---------------------------------------------------- */
 

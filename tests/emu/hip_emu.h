@@ -134,6 +134,7 @@ inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : 2; }
 inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
 inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, int) { std::memcpy(d, s, n); return hipSuccess; }
