@@ -488,7 +488,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   s->off_wp = place(sizeof(WpTables));
   const size_t upload_bytes = off;
   s->upload_bytes = upload_bytes;
-  s->off_rec4 = place(k.rec4.size() * sizeof(Part4));  // device only: expanded from the runs after the copy
+  s->off_rec4 = place((size_t)k.n_rec4 * sizeof(Part4));  // device only: expanded from the runs after the copy
   const size_t total = off;
   if (s->dev_cap < total) {
     for (int k = 0; k < kCopyStreams; k++) HIPCHK(c, hipStreamSynchronize(c->copy_stream[k]));
@@ -565,9 +565,10 @@ extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[32]
   out[11] = (int64_t)k.ictu.size();
   out[12] = (int64_t)k.lvl_counts.size();
   out[7] = k.mc_ref_samples;
-  out[8] = (int64_t)k.rec4.size();
+  out[8] = k.finished ? k.n_rec4 : (int64_t)k.rec4.size();
   int64_t intra4 = 0;
   for (size_t i = 0; i < k.rec4.size(); i++) intra4 += (k.rec4[i].flags & P4_INTRA) ? 1 : 0;
+  if (k.finished) intra4 = k.n_rec4_intra;
   out[9] = intra4;
   out[29] = (int64_t)s->upload_bytes;
   out[30] = (int64_t)k.runs.size();

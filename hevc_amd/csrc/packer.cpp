@@ -60,6 +60,7 @@ void PackedPicture::begin(const SeqInfo &s) {
   use_wp = false;
   has_bypass = false;
   has_pcm = false;
+  n_rec4 = n_rec4_intra = 0;
   mc_ref_samples = 0;
   max_ref_idx[0] = max_ref_idx[1] = -1;
   inter_without_ref = false;
@@ -401,6 +402,14 @@ bool PackedPicture::finish(const hevcrecon_pic_params *p) {
   ictu.swap(sorted);
   build_mc_lists();
   build_runs();
+  n_rec4 = (int64_t)rec4.size();
+  n_rec4_intra = 0;
+  for (size_t i = 0; i < rec4.size(); i++) n_rec4_intra += (rec4[i].flags & P4_INTRA) ? 1 : 0;
+  // The per-unit working arrays (2.6 MB at 1080p) are not needed any more; a host that keeps thousands of packed
+  // pictures around should not pay for them.
+  std::vector<Part4>().swap(rec4);
+  std::vector<uint16_t>().swap(lvl_y);
+  std::vector<uint16_t>().swap(lvl_c);
   finished = true;
   return true;
 }

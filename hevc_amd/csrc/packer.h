@@ -12,7 +12,8 @@
 struct PackedPicture {
   SeqInfo seq;
   hevcrecon_pic_params pp;
-  std::vector<Part4> rec4;
+  std::vector<Part4> rec4;          // working copy while the picture is packed; released by finish() (the runs carry it on)
+  int64_t n_rec4, n_rec4_intra;     // records inside the picture, and how many of them are intra
   std::vector<TuItem> tu[4];
   // Coded coefficients, sparse: per transform block one header word (number of non-zero coefficients) followed by
   // that many words (position inside the block, raster) | (value << 16)
