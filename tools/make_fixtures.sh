@@ -27,6 +27,8 @@ $E -c $cfg/encoder_lowdelay_P_main.cfg -i f240.yuv -wdt 416 -hgt 240 -fr 30 -f 9
 $E -c $cfg/encoder_randomaccess_he10.cfg -i f240.yuv -wdt 416 -hgt 240 -fr 30 -f 9 -b wpb_240.bin -o /dev/null --SEIpictureDigest=1 -wpP 1 -wpB 1 > wpb_240.enc.log &
 # constrained intra prediction; the noise patch yields intra blocks inside the B pictures
 $E -c $cfg/encoder_randomaccess_main.cfg -i n6.yuv -wdt 416 -hgt 240 -fr 30 -f 6 -q 30 -b cip_240.bin -o /dev/null --SEIpictureDigest=1 --ConstrainedIntraPred=1 > cip_240.enc.log &
+# 12-bit internal bit depth
+$E -c $cfg/encoder_randomaccess_he10.cfg -i c240.yuv -wdt 416 -hgt 240 -fr 30 -f 5 -b bd12_240.bin -o /dev/null --SEIpictureDigest=1 --InternalBitDepth=12 > bd12_240.enc.log &
 # IPCM: noise patch at QP 6; 10-bit with 8-bit PCM samples and the in-loop filters off for IPCM units, 8-bit with them on
 $E -c $cfg/encoder_randomaccess_he10.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 5 -q 6 -b pcm_240.bin -o /dev/null --SEIpictureDigest=1 --PCMEnabledFlag=1 --PCMFilterDisableFlag=1 > pcm_240.enc.log &
 $E -c $cfg/encoder_lowdelay_P_main.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 4 -q 6 -b pcmlf_240.bin -o /dev/null --SEIpictureDigest=1 --PCMEnabledFlag=1 --PCMFilterDisableFlag=0 > pcmlf_240.enc.log &
@@ -35,7 +37,7 @@ $E -c $cfg/encoder_randomaccess_he10.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30
 $E -c $cfg/encoder_intra_main.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 16 -b intra_main_1080.bin -o /dev/null --SEIpictureDigest=1 > intra_main_1080.enc.log &
 wait
 D="$root/oracle/_ref/TAppDecoderBridge"
-for s in lowdelay_P_main_240 randomaccess_main_240 randomaccess_he10_240 intra_main_240 scalinglist_240 lossless_240 pcm_240 pcmlf_240 wpp_240 wpb_240 cip_240 ra_main_1080 ra_he10_1080 intra_main_1080; do
+for s in lowdelay_P_main_240 randomaccess_main_240 randomaccess_he10_240 intra_main_240 scalinglist_240 lossless_240 pcm_240 pcmlf_240 wpp_240 wpb_240 cip_240 bd12_240 ra_main_1080 ra_he10_1080 intra_main_1080; do
   HEVCRECON_MODE=dump HEVCRECON_DUMP=$s.syn $D -b $s.bin > $s.dec.log
 done
 cd "$root" && python - <<'PY'
@@ -44,7 +46,7 @@ from hevc_amd import syntax
 names = {"lowdelay_P_main_240": "lowdelay_P_main_416x240", "randomaccess_main_240": "randomaccess_main_416x240",
          "randomaccess_he10_240": "randomaccess_he10_416x240", "intra_main_240": "intra_main_416x240",
          "scalinglist_240": "scalinglist_416x240", "lossless_240": "lossless_416x240",
-         "pcm_240": "pcm_416x240", "pcmlf_240": "pcmlf_416x240", "wpp_240": "wpp_416x240", "wpb_240": "wpb_416x240", "cip_240": "cip_416x240",
+         "pcm_240": "pcm_416x240", "pcmlf_240": "pcmlf_416x240", "wpp_240": "wpp_416x240", "wpb_240": "wpb_416x240", "cip_240": "cip_416x240", "bd12_240": "bd12_416x240",
          "ra_main_1080": "randomaccess_main_1920x1080", "ra_he10_1080": "randomaccess_he10_1920x1080",
          "intra_main_1080": "intra_main_1920x1080"}
 keys = {"ra_main_1080": "randomaccess_main_1080", "ra_he10_1080": "randomaccess_he10_1080"}
@@ -59,7 +61,7 @@ for src, dst in names.items():
             rows.append([int(m.group(1)), m.group(2), m.group(3), m.group(4)])
     md5[keys.get(src, src)] = rows
 json.dump(md5, open("tests/golden/hm_md5.json", "w"), indent=0)
-for b in ["lowdelay_P_main_240", "randomaccess_main_240", "randomaccess_he10_240", "intra_main_240", "scalinglist_240", "lossless_240", "pcm_240", "pcmlf_240", "wpp_240", "wpb_240", "cip_240"]:
+for b in ["lowdelay_P_main_240", "randomaccess_main_240", "randomaccess_he10_240", "intra_main_240", "scalinglist_240", "lossless_240", "pcm_240", "pcmlf_240", "wpp_240", "wpb_240", "cip_240", "bd12_240"]:
     shutil.copy("work/%s.bin" % b, "tests/golden/%s.bin" % b)
 shutil.copy("work/ra_main_1080.bin", "tests/golden/randomaccess_main_1080.bin")
 PY
