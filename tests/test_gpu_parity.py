@@ -127,7 +127,11 @@ def test_all_stages_md5_exact_1080p(stream):
     eng.close()
 
 
-@pytest.mark.parametrize("bits,npics", [("lowdelay_P_main_240", 9), ("randomaccess_he10_240", 9), ("scalinglist_240", 9), ("lossless_240", 6), ("pcm_240", 5), ("pcmlf_240", 4), ("wpp_240", 9), ("wpb_240", 9), ("cip_240", 6), ("bd12_240", 5), ("randomaccess_main_1080", 60)])
+@pytest.mark.parametrize("bits,npics", [("lowdelay_P_main_240", 9), ("randomaccess_he10_240", 9), ("scalinglist_240", 9), ("lossless_240", 6), ("pcm_240", 5), ("pcmlf_240", 4), ("wpp_240", 9), ("wpb_240", 9), ("cip_240", 6), ("bd12_240", 5), ("randomaccess_main_1080", 60),
+                                        # encoder option sweep (tools/make_fixtures.sh): per-CU QP changes + chroma QP offsets + deblocking
+                                        # offsets; QP 22 with picture-based SAO; QP 45 without deblocking; transform trees of depth 3
+                                        # without AMP / SAO / transform skip; low-delay B
+                                        ("sweep_dqp", 5), ("sweep_q22", 4), ("sweep_q45", 5), ("sweep_tu", 5), ("sweep_lb", 6)])
 def test_drop_in_behind_reference_decoder_cli(bits, npics):
     """The reference decoder's own CLI with its reconstruction call sites redirected to the engine
     (oracle/_ref/TAppDecoderBridge, HEVCRECON_MODE=engine): the reference parses, the GPU reconstructs, and the

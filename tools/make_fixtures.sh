@@ -35,7 +35,15 @@ $E -c $cfg/encoder_lowdelay_P_main.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 4
 $E -c $cfg/encoder_randomaccess_main.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 60 -b ra_main_1080.bin -o /dev/null --SEIpictureDigest=1 > ra_main_1080.enc.log &
 $E -c $cfg/encoder_randomaccess_he10.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 25 -b ra_he10_1080.bin -o /dev/null --SEIpictureDigest=1 > ra_he10_1080.enc.log &
 $E -c $cfg/encoder_intra_main.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 16 -b intra_main_1080.bin -o /dev/null --SEIpictureDigest=1 > intra_main_1080.enc.log &
+# option sweep: bitstreams only, decoded through the reference decoder's CLI with the engine behind it
+sw() { name=$1; shift; $E "$@" -wdt 416 -hgt 240 -fr 30 -b sweep_$name.bin -o /dev/null --SEIpictureDigest=1 > sweep_$name.enc.log; }
+sw dqp -c $cfg/encoder_randomaccess_main.cfg -i c240.yuv -f 5 --MaxDeltaQP=4 --MaxCuDQPDepth=2 --CbQpOffset=3 --CrQpOffset=-4 --DeblockingFilterControlPresent=1 --LoopFilterBetaOffset_div2=2 --LoopFilterTcOffset_div2=-1 &
+sw q22 -c $cfg/encoder_lowdelay_P_main.cfg -i n240.yuv -f 4 -q 22 --SAOLcuBasedOptimization=0 &
+sw q45 -c $cfg/encoder_randomaccess_he10.cfg -i c240.yuv -f 5 -q 45 --LoopFilterDisable=1 &
+sw tu -c $cfg/encoder_randomaccess_main.cfg -i n240.yuv -f 5 -q 27 --QuadtreeTUMaxDepthIntra=3 --QuadtreeTUMaxDepthInter=3 --AMP=0 --SAO=0 --TransformSkip=0 &
+sw lb -c $cfg/encoder_lowdelay_main.cfg -i f240.yuv -f 6 -q 30 &
 wait
+for n in dqp q22 q45 tu lb; do cp sweep_$n.bin "$root/tests/golden/"; done
 D="$root/oracle/_ref/TAppDecoderBridge"
 for s in lowdelay_P_main_240 randomaccess_main_240 randomaccess_he10_240 intra_main_240 scalinglist_240 lossless_240 pcm_240 pcmlf_240 wpp_240 wpb_240 cip_240 bd12_240 ra_main_1080 ra_he10_1080 intra_main_1080; do
   HEVCRECON_MODE=dump HEVCRECON_DUMP=$s.syn $D -b $s.bin > $s.dec.log
