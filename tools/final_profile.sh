@@ -18,5 +18,6 @@ bash tools/pmc_passes.sh 128
 python3 tools/pmc_summary.py gpurun_out/pmc > $O/pmc_summary.txt
 python3 tools/pmc_traffic.py gpurun_out/pmc 128 randomaccess_main_1920x1080 > $O/hbm_traffic.json
 rm -rf gpurun_out/pmc/p*/
+cp $O/hbm_traffic.json profiles/hbm_traffic.json  # the bench line below reads its roofline.traffic from there
 timeout -k 10 500 python3 -u bench.py > $O/bench.log 2>&1
 tail -1 $O/bench.log > $O/bench.json
