@@ -1672,65 +1672,73 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
   const SaoCtu sp = J.sao[((size_t)(y >> csh) * s.ctus_w + (x >> csh)) * 3 + comp];
   const bool on = (comp ? J.sao_chroma : J.sao_luma) && sp.type >= 0;
   const int inc = bd > 10 ? bd - 10 : 0;
+  // Everything that depends on the CTU's parameters is data, not control flow (the 64 lanes of a wave span 16 CTUs):
+  //   edge offset: neighbour a lies towards (-dx,-dy), b towards (+dx,+dy); class = sign(c-a) + sign(c-b) + 2 picks a byte
+  //                of `table` (offsets 0 and 1, zero, offsets 2 and 3); rows at the top / bottom picture border and lanes
+  //                without SAO get an all-zero table, the two samples at the left / right border are put back afterwards
+  //   band offset: band index relative to the first band picks a byte of `table` (the four offsets, then zeros)
+  const bool eo = on && sp.type < 4, bo = on && sp.type == 4;
+  const int dx = !eo || sp.type == 1 ? 0 : (sp.type == 3 ? -1 : 1), dy = eo && sp.type != 0 ? 1 : 0;
+  const bool rows_ok = dy == 0 || (y > 0 && y + 1 < ph);
+  unsigned long long table = 0;
+  if (eo && rows_ok)
+    table = (unsigned long long)(uint8_t)sp.offset[0] | ((unsigned long long)(uint8_t)sp.offset[1] << 8) |
+            ((unsigned long long)(uint8_t)sp.offset[2] << 24) | ((unsigned long long)(uint8_t)sp.offset[3] << 32);
+  if (bo)
+    table = (unsigned long long)(uint8_t)sp.offset[0] | ((unsigned long long)(uint8_t)sp.offset[1] << 8) |
+            ((unsigned long long)(uint8_t)sp.offset[2] << 16) | ((unsigned long long)(uint8_t)sp.offset[3] << 24);
+  const int dyr = dy && rows_ok ? stride : 0;
   const pel_t *row = src + (size_t)y * stride;
-  // samples x-1 .. x+16 of one row.  Reads past the picture width stay inside the padded row (or the slack
+  // A row's samples x-4/B .. x+16+4/B-1 as packed dwords (B = bytes per sample): one dword left of the lane's 16
+  // samples, the samples, one dword right.  Reads past the picture width stay inside the padded row (or the slack
   // after the last plane) and are never used: such neighbours make the sample a border sample.
-  auto fetch18 = [&](const pel_t *rp, int o[18]) {
-    if constexpr (sizeof(pel_t) == 1) {
-      const uint4 m = *(const uint4 *)(rp + x);
-      const unsigned l = x > 0 ? *(const unsigned *)(rp + x - 4) : 0u;
-      const unsigned r = *(const unsigned *)(rp + x + 16);
-      const unsigned w[4] = {m.x, m.y, m.z, m.w};
-      o[0] = (int)(l >> 24);
+  constexpr int SPD = 4 / sizeof(pel_t);   // samples per dword
+  constexpr int ND = 16 / SPD;             // dwords holding the lane's 16 samples
+  auto fetch = [&](const pel_t *rp, unsigned w[ND + 2]) {
+    w[0] = x > 0 ? *(const unsigned *)(rp + x - SPD) : 0u;
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) o[1 + 4 * k + i] = (int)((w[k] >> (8 * i)) & 255);
-      o[17] = (int)(r & 255);
-    } else {
-      // 16 samples as two 16-byte vectors plus the two neighbours (rows are padded, see above)
-      const uint4 m0 = *(const uint4 *)(rp + x), m1 = *(const uint4 *)(rp + x + 8);
-      const unsigned w[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-      o[0] = x > 0 ? (int)rp[x - 1] : 0;
-#pragma unroll
-      for (int i = 0; i < 16; i++) o[1 + i] = (int)((w[i >> 1] >> (16 * (i & 1))) & 0xffff);
-      o[17] = (int)rp[x + 16];
+    for (int k = 0; k < ND / 4; k++) {
+      const uint4 m = *(const uint4 *)(rp + x + 4 * SPD * k);
+      w[1 + 4 * k] = m.x, w[2 + 4 * k] = m.y, w[3 + 4 * k] = m.z, w[4 + 4 * k] = m.w;
     }
+    w[ND + 1] = *(const unsigned *)(rp + x + 16);
   };
-  int cur[18], v[16];
-  fetch18(row, cur);
-  if (on && sp.type < 4) {
-    // edge offset: a = neighbour towards (-dx,-dy), b = towards (+dx,+dy); picture-border samples stay as they are
-    const int dx = sp.type == 1 ? 0 : (sp.type == 3 ? -1 : 1), dy = sp.type == 0 ? 0 : 1;
-    int up[18], dn[18];
-    const bool rows_ok = dy == 0 || (y > 0 && y + 1 < ph);
-    if (dy && rows_ok) {
-      fetch18(row - stride, up);
-      fetch18(row + stride, dn);
-    } else {
+  // the 16 samples starting `shift` samples (-1, 0, 1) from the lane's first one, still packed
+  auto shifted = [&](const unsigned w[ND + 2], int shift, unsigned o[ND]) {
+    const bool back = shift < 0;
+    const int bytes = shift == 0 ? 0 : (back ? 4 - (int)sizeof(pel_t) : (int)sizeof(pel_t));
+    unsigned lo[ND + 1];
 #pragma unroll
-      for (int i = 0; i < 18; i++) up[i] = dn[i] = cur[i];
-    }
+    for (int k = 0; k <= ND; k++) lo[k] = back ? w[k] : w[k + 1];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const int c = cur[i + 1];
-      const int a = dx == 0 ? up[i + 1] : (dx > 0 ? up[i] : up[i + 2]);
-      const int b = dx == 0 ? dn[i + 1] : (dx > 0 ? dn[i + 2] : dn[i]);
-      const bool border = !rows_ok || x + i - dx < 0 || x + i - dx >= pw || x + i + dx < 0 || x + i + dx >= pw;
-      const int e = (c > a) - (c < a) + (c > b) - (c < b);  // -2..2
-      const int o = e == -2 ? sp.offset[0] : e == -1 ? sp.offset[1] : e == 1 ? sp.offset[2] : e == 2 ? sp.offset[3] : 0;
-      v[i] = border ? c : clip3i(0, maxv, c + (o << inc));
-    }
-  } else {
+    for (int k = 0; k < ND; k++) o[k] = hr_alignbyte(lo[k + 1], lo[k], bytes);
+  };
+  auto sample = [&](const unsigned w[ND], int i) -> int {
+    return sizeof(pel_t) == 1 ? (int)((w[i >> 2] >> (8 * (i & 3))) & 255u) : (int)((w[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+  };
+  unsigned wc[ND + 2], wa[ND + 2], wb[ND + 2], pc[ND], pa[ND], pb[ND];
+  fetch(row, wc);
+  fetch(row - dyr, wa);
+  fetch(row + dyr, wb);
+  shifted(wc, 0, pc);
+  shifted(wa, -dx, pa);
+  shifted(wb, dx, pb);
+  int v[16];
+  const int bsh = bd - 5, band0 = sp.band;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      int c = cur[i + 1];
-      if (on) {  // band offset
-        const int k = ((c >> (bd - 5)) - sp.band) & 31;
-        const int o = k == 0 ? sp.offset[0] : k == 1 ? sp.offset[1] : k == 2 ? sp.offset[2] : k == 3 ? sp.offset[3] : 0;
-        c = clip3i(0, maxv, c + (o << inc));
-      }
-      v[i] = c;
+  for (int i = 0; i < 16; i++) {
+    const int c = sample(pc, i);
+    const int cls = clip3i(-1, 1, c - sample(pa, i)) + clip3i(-1, 1, c - sample(pb, i)) + 2;  // 2 for lanes without edge offset
+    const int idx = bo ? min(((c >> bsh) - band0) & 31, 4) : cls;
+    const int o = (int)(int8_t)(uint8_t)(table >> (8 * idx));
+    v[i] = clip3i(0, maxv, c + (o << inc));
+  }
+  if (dx != 0) {  // picture-border samples of the horizontal and diagonal classes stay as they are
+    if (x == 0) v[0] = sample(pc, 0);
+    if (x + 16 >= pw) {
+#pragma unroll
+      for (int i = 0; i < 16; i++)
+        if (x + i == pw - 1) v[i] = sample(pc, i);
     }
   }
   if (J.has_bypass) {
@@ -1741,7 +1749,7 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int ux = (x + i) >> ush;
-      if (ux < s.uw && (J.rec4[(size_t)uy * s.uw + ux].flags & P4_BYPASS)) v[i] = cur[i + 1];
+      if (ux < s.uw && (J.rec4[(size_t)uy * s.uw + ux].flags & P4_BYPASS)) v[i] = sample(pc, i);
     }
   }
   pel_t *orow = dst + (size_t)y * stride + x;
@@ -1759,9 +1767,17 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
         if (x + 4 * q < pw) *(unsigned *)(orow + 4 * q) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
   } else {
+    if (x + 16 <= pw) {
+      uint4 o0, o1;
+      o0.x = pack16(v[0], v[1]), o0.y = pack16(v[2], v[3]), o0.z = pack16(v[4], v[5]), o0.w = pack16(v[6], v[7]);
+      o1.x = pack16(v[8], v[9]), o1.y = pack16(v[10], v[11]), o1.z = pack16(v[12], v[13]), o1.w = pack16(v[14], v[15]);
+      ((uint4 *)orow)[0] = o0;
+      ((uint4 *)orow)[1] = o1;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-      if (x + i < pw) orow[i] = (pel_t)v[i];
+      for (int i = 0; i < 16; i++)
+        if (x + i < pw) orow[i] = (pel_t)v[i];
+    }
   }
 }
 
