@@ -76,6 +76,7 @@ class CtuSyntax(C.Structure):
         ("sao_subtype", C.c_int32 * 3),
         ("sao_offset", (C.c_int32 * 4) * 3),
         ("pcm", C.c_void_p * 3),
+        ("slice_start", C.c_void_p),
     ]
 
 

@@ -282,7 +282,13 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
   const int my_cx = ux0 >> 4, my_cy = uy0 >> 4;
   // A unit of ANOTHER CTU matters only when an intra block covers it: then this CTU has to wait for that CTU's
   // wave (inter samples are final before any intra kernel runs).
-  auto usable = [&](int ux, int uy) -> bool { return coding_order(ux, uy) < cur; };
+  // ... and, when it lies in another CTU, not before the start of this block's slice (TComDataCU::getPULeft and
+  // friends check the slice only when they leave the CTU)
+  const int slice_start = ctu->slice_start ? (int)ctu->slice_start[z] : 0;
+  auto usable = [&](int ux, int uy) -> bool {
+    const int o = coding_order(ux, uy);
+    return o < cur && (o >= slice_start || (o >> 8) == (cur >> 8));
+  };
   auto is_intra = [&](int ux, int uy) -> bool { return (rec4[(size_t)uy * seq.uw + ux].flags & P4_INTRA) != 0; };
   IntraNeighbours nb = {0, 0, 0};
   auto level_at = [&](int ux, int uy) -> int {

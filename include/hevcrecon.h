@@ -109,6 +109,12 @@ typedef struct hevcrecon_ctu_syntax {
   /* TComDataCU::getPCMSampleY/Cb/Cr (Pel arrays laid out like coeff[]: offset 16*absPartIdx luma, 4*absPartIdx
    * chroma, raster inside the coding unit); read only for partitions whose ipcm flag is set; may be NULL */
   const int16_t *pcm[3];
+  /* TComDataCU::getSliceStartCU per partition: address (CTU address * 256 + z index) of the first partition of the
+   * slice the partition belongs to.  Intra prediction does not use neighbours of other CTUs that lie before it
+   * (TComDataCU::getPULeft / getPUAbove / ... with bEnforceSliceRestriction, TLibCommon/TComDataCU.cpp:1141-1589).
+   * NULL: one slice.  The slices of a picture must agree in everything hevcrecon_pic_params carries, and filter
+   * across their boundaries (slice_loop_filter_across_slices_enabled_flag = 1). */
+  const uint32_t *slice_start;
 } hevcrecon_ctu_syntax;
 
 /* Scaling lists in effect for a picture: the TComScalingList that TDecTop::xDecodeSlice has resolved from

@@ -210,9 +210,35 @@ struct Bridge {
     return true;
   }
 
-  void fill_ctu(TComPic *pic, int addr, const hevcrecon_pic_params &pp, hevcrecon_ctu_syntax &cs, int8_t *refbuf) {
+  // Several slices per picture are handed over as one set of picture parameters: they have to agree in everything
+  // those carry, and filter across their boundaries.
+  void check_slices(TComPic *pic) {
+    TComSlice *a = pic->getSlice(pic->getCurrSliceIdx());
+    for (UInt i = 0; i < pic->getNumAllocatedSlice() && i <= pic->getCurrSliceIdx(); i++) {
+      TComSlice *b = pic->getSlice(i);
+      bool same = a->getSliceType() == b->getSliceType() && a->getDeblockingFilterDisable() == b->getDeblockingFilterDisable() &&
+                  a->getDeblockingFilterBetaOffsetDiv2() == b->getDeblockingFilterBetaOffsetDiv2() &&
+                  a->getDeblockingFilterTcOffsetDiv2() == b->getDeblockingFilterTcOffsetDiv2() &&
+                  a->getSliceQpDeltaCb() == b->getSliceQpDeltaCb() && a->getSliceQpDeltaCr() == b->getSliceQpDeltaCr() &&
+                  a->getSaoEnabledFlag() == b->getSaoEnabledFlag() && a->getSaoEnabledFlagChroma() == b->getSaoEnabledFlagChroma() &&
+                  b->getLFCrossSliceBoundaryFlag();
+      for (int l = 0; same && l < 2; l++) {
+        same = a->getNumRefIdx(RefPicList(l)) == b->getNumRefIdx(RefPicList(l));
+        for (int r = 0; same && !a->isIntra() && r < a->getNumRefIdx(RefPicList(l)); r++)
+          same = a->getRefPic(RefPicList(l), r) == b->getRefPic(RefPicList(l), r);
+      }
+      if (!same) {
+        fprintf(stderr, "hm_bridge: the slices of POC %d differ in their slice-level parameters or do not filter across slice boundaries\n", a->getPOC());
+        exit(EXIT_FAILURE);
+      }
+    }
+  }
+
+  void fill_ctu(TComPic *pic, int addr, const hevcrecon_pic_params &pp, hevcrecon_ctu_syntax &cs, int8_t *refbuf, uint32_t *slicebuf) {
     TComDataCU *cu = pic->getCU(addr);
     memset(&cs, 0, sizeof(cs));
+    for (int i = 0; i < HEVCRECON_PARTS_PER_CTU; i++) slicebuf[i] = cu->getSliceStartCU(i);
+    cs.slice_start = slicebuf;
     cs.depth = cu->getDepth();
     cs.pred_mode = (const int8_t *)cu->getPredictionMode();
     cs.part_size = (const int8_t *)cu->getPartitionSize();
@@ -290,6 +316,7 @@ struct Bridge {
     }
     hevcrecon_pic_params pp;
     fill_pic(pic, pp);
+    check_slices(pic);
     int nctu = pic->getNumCUsInFrame();
     hevcrecon_scaling_lists sl;
     if (fill_scaling(pic, sl)) {  // optional record in front of the picture
@@ -299,8 +326,19 @@ struct Bridge {
     }
     std::vector<hevcrecon_ctu_syntax> cs(nctu);
     std::vector<int8_t> refbuf(nctu * 2 * HEVCRECON_PARTS_PER_CTU);
-    for (int a = 0; a < nctu; a++) fill_ctu(pic, a, pp, cs[a], &refbuf[a * 2 * HEVCRECON_PARTS_PER_CTU]);
+    std::vector<uint32_t> slicebuf(nctu * HEVCRECON_PARTS_PER_CTU);
+    for (int a = 0; a < nctu; a++)
+      fill_ctu(pic, a, pp, cs[a], &refbuf[a * 2 * HEVCRECON_PARTS_PER_CTU], &slicebuf[a * HEVCRECON_PARTS_PER_CTU]);
     const int P = HEVCRECON_PARTS_PER_CTU;
+    {  // optional record in front of the picture: slice start addresses, when there is more than one slice
+      bool any = false;
+      for (size_t i = 0; i < slicebuf.size() && !any; i++) any = slicebuf[i] != 0;
+      if (any) {
+        int32_t shdr[4] = {0x54534C53 /* "SLST" */, nctu, 0, 0};
+        put(shdr, 4);
+        put(&slicebuf[0], slicebuf.size());
+      }
+    }
     {  // optional record in front of the picture: the PCM sample arrays of the CTUs that hold IPCM units
       std::vector<int32_t> with_pcm;
       for (int a = 0; a < nctu; a++) {
@@ -376,6 +414,7 @@ struct Bridge {
     if (!syn && api.syntax_create(ctx, &syn)) fail("hevcrecon_syntax_create");
     hevcrecon_pic_params pp;
     fill_pic(pic, pp);
+    check_slices(pic);
     if (api.syntax_begin(syn)) fail("hevcrecon_syntax_begin");
     hevcrecon_scaling_lists sl;
     if (fill_scaling(pic, sl) && api.syntax_set_scaling_lists(syn, &sl)) fail("hevcrecon_syntax_set_scaling_lists");
@@ -385,7 +424,8 @@ struct Bridge {
     for (int a = 0; a < nctu; a++) {
       hevcrecon_ctu_syntax cs;
       int8_t refbuf[2 * HEVCRECON_PARTS_PER_CTU];
-      fill_ctu(pic, a, pp, cs, refbuf);
+      uint32_t slicebuf[HEVCRECON_PARTS_PER_CTU];
+      fill_ctu(pic, a, pp, cs, refbuf, slicebuf);
       if (api.syntax_add_ctu(syn, a, &cs)) fail("hevcrecon_syntax_add_ctu");
     }
     if (api.syntax_finish(syn, &pp)) fail("hevcrecon_syntax_finish");

@@ -451,7 +451,7 @@ static inline int coding_order(const hevcref_ctx *c, int ux, int uy) {
  * TComDataCU::getPULeft/Above/AboveLeft/AboveRightAdi/BelowLeftAdi (TLibCommon/TComDataCU.cpp:1141-1589)
  * for one slice, one tile, unconstrained intra: a 4x4 unit is available iff it lies inside the
  * picture and precedes the current block in coding order. */
-static void build_intra_refs(const hevcref_ctx *c, int comp, int x0, int y0, int n, int *ref) {
+static void build_intra_refs(const hevcref_ctx *c, int comp, int x0, int y0, int n, int slice_start, int *ref) {
   int sh = comp ? 1 : 0, us = 4 >> sh; /* unit size in samples of this plane */
   int pw = plane_w(c, comp), ph = plane_h(c, comp);
   const int16_t *p = c->rec[comp];
@@ -472,7 +472,14 @@ static void build_intra_refs(const hevcref_ctx *c, int comp, int x0, int y0, int
       sy = y0 - 1;
     }
     int ok = sx >= 0 && sy >= 0 && sx < pw && sy < ph;
-    if (ok) ok = coding_order(c, (sx << sh) >> 2, (sy << sh) >> 2) < cur;
+    if (ok) {
+      int o = coding_order(c, (sx << sh) >> 2, (sy << sh) >> 2);
+      ok = o < cur;
+      /* neighbours in another CTU must belong to the block's slice (bEnforceSliceRestriction in TComDataCU::getPULeft,
+       * getPUAbove, getPUAboveLeft, getPUAboveRightAdi, getPUBelowLeftAdi, TLibCommon/TComDataCU.cpp:1141-1589; no
+       * such check for neighbours inside the CTU) */
+      if (ok && (o >> 8) != (cur >> 8)) ok = o >= slice_start;
+    }
     if (ok && c->pp->constrained_intra_pred) { /* TComPattern::is*Available with constrained intra prediction */
       PartRef nb = part_at(c, sx << sh, sy << sh);
       ok = nb.ctu->pred_mode[nb.z] == 1;
@@ -634,7 +641,7 @@ static void intra_block(hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int zcu
                         int log2, int mode) {
   int n = 1 << log2;
   int ref[4 * 32 + 1], fref[4 * 32 + 1];
-  build_intra_refs(c, comp, x0, y0, n, ref);
+  build_intra_refs(c, comp, x0, y0, n, ctu->slice_start ? (int)ctu->slice_start[z] : 0, ref);
   const int *use = ref;
   if (comp == 0 && mode != 1) { /* TComPattern::getPredictorPtr, TLibCommon/TComPattern.cpp:627-651 */
     static const int thr[4] = {10, 7, 1, 0};

@@ -145,3 +145,18 @@ def test_constraint_is_what_makes_the_cip_stream_match():
     ref.reconstruct(pic)
     luma = ref.download(2, pic.pic_id)[0]
     assert syntax.plane_md5(luma, seq.seq_params.bit_depth_luma) != pic.stage_md5[2][0]
+
+
+def test_slice_starts_are_what_makes_the_slices_stream_match():
+    """Negative control for the multi-slice fixture: treated as one slice, its first picture must NOT match."""
+    import copy
+
+    seq = load_golden("slices_416x240", 1)
+    pic = copy.copy(seq.pictures[0])
+    assert pic.slice_start is not None and len(set(pic.slice_start.ravel().tolist())) == 6
+    pic.slice_start = None
+    pic._keep = None
+    ref = RefModel(seq.seq_params)
+    ref.reconstruct(pic)
+    luma = ref.download(2, pic.pic_id)[0]
+    assert syntax.plane_md5(luma, seq.seq_params.bit_depth_luma) != pic.stage_md5[2][0]
