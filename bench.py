@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the picture-reconstruction engine on MI355X.
 
-Workload (BASELINE.json configs[2]): the 1920x1080, 60-frame random-access stream encoded by the reference
+Workload: the 1920x1080, 60-frame random-access stream encoded by the reference
 encoder (cfg/encoder_randomaccess_main.cfg) from the synthetic clip of tools/gen_clip.py, as parsed by the
 reference decoder (tests/golden/randomaccess_main_1920x1080.syn.xz).  Each GPU reconstructs `--streams`
 independent copies of that stream (the stream-sharded multi-stream case), pictures of equal decoding

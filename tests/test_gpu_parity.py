@@ -109,7 +109,7 @@ def test_packed_pictures_can_be_uploaded_again():
 
 @pytest.mark.parametrize("stream", ["randomaccess_main", "randomaccess_he10", "intra_main"])
 def test_all_stages_md5_exact_1080p(stream):
-    """BASELINE configs 2-4 at full size: every picture's three stages against the MD5s of the reference
+    """The 1080p streams (all-intra, random access, 10-bit random access) at full size: every picture's three stages against the MD5s of the reference
     decoder's own pictures (before deblocking, after deblocking, final = the digest it checks against the SEI)."""
     seq = load_golden(stream + "_1920x1080")
     bd = bit_depths(seq)

@@ -64,7 +64,7 @@ STREAMS_1080 = [("randomaccess_main", 60), ("randomaccess_he10", 25), ("intra_ma
 
 @pytest.mark.parametrize("stream,npics", STREAMS_1080)
 def test_oracle_matches_reference_1080p(stream, npics):
-    """Full-size streams (BASELINE configs 2-4): every picture, every stage, against the reference decoder."""
+    """Full-size 1080p streams (all-intra, random access, 10-bit random access): every picture, every stage, against the reference decoder."""
     seq = load_golden(stream + "_1920x1080")
     bd = bit_depths(seq)
     hm = json.load(open(os.path.join(GOLDEN, "hm_md5.json")))[stream + "_1080"]
