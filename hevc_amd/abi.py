@@ -77,6 +77,8 @@ class CtuSyntax(C.Structure):
         ("sao_offset", (C.c_int32 * 4) * 3),
         ("pcm", C.c_void_p * 3),
         ("slice_start", C.c_void_p),
+        ("coding_addr_plus1", C.c_int32),
+        ("tile_id", C.c_int32),
     ]
 
 

@@ -65,21 +65,27 @@ void PackedPicture::begin(const SeqInfo &s) {
   max_ref_idx[0] = max_ref_idx[1] = -1;
   inter_without_ref = false;
   next_ctu = 0;
+  ctu_order.assign((size_t)s.ctus_w * s.ctus_h, -1);
+  ctu_tile.assign((size_t)s.ctus_w * s.ctus_h, 0);
   finished = false;
   error.clear();
 }
 
-// Position in coding order of the 4x4 unit (ux, uy): CTUs in raster order, z-order inside.
+// Position in coding order of the 4x4 unit (ux, uy): CTUs in the order they were added (raster, or tile scan),
+// z-order inside.  Units of CTUs that have not been added yet come after everything.
 int PackedPicture::coding_order(int ux, int uy) const {
-  return ((uy >> 4) * seq.ctus_w + (ux >> 4)) * 256 + kZ.z[uy & 15][ux & 15];
+  const int o = ctu_order[(size_t)(uy >> 4) * seq.ctus_w + (ux >> 4)];
+  return o < 0 ? 0x7fffffff : o * 256 + kZ.z[uy & 15][ux & 15];
 }
 
 bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
-  if (finished || addr != next_ctu || addr >= seq.ctus_w * seq.ctus_h) {
-    error = "CTUs must be added once each, in raster order";
+  if (finished || addr < 0 || addr >= seq.ctus_w * seq.ctus_h || ctu_order[addr] >= 0 ||
+      (ctu->coding_addr_plus1 ? ctu->coding_addr_plus1 - 1 : addr) != next_ctu) {
+    error = "CTUs must be added once each, in coding order";
     return false;
   }
-  next_ctu++;
+  ctu_order[addr] = next_ctu++;
+  ctu_tile[addr] = ctu->tile_id;
   for (int c = 0; c < 3; c++) {
     SaoCtu &s = sao[(size_t)addr * 3 + c];
     s.type = (int8_t)ctu->sao_type[c];
@@ -282,12 +288,15 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
   const int my_cx = ux0 >> 4, my_cy = uy0 >> 4;
   // A unit of ANOTHER CTU matters only when an intra block covers it: then this CTU has to wait for that CTU's
   // wave (inter samples are final before any intra kernel runs).
-  // ... and, when it lies in another CTU, not before the start of this block's slice (TComDataCU::getPULeft and
-  // friends check the slice only when they leave the CTU)
+  // ... and, when it lies in another CTU, not before the start of this block's slice and in the same tile
+  // (TComDataCU::getPULeft and friends check slice and tile only when they leave the CTU)
   const int slice_start = ctu->slice_start ? (int)ctu->slice_start[z] : 0;
+  const int my_tile = ctu->tile_id;
   auto usable = [&](int ux, int uy) -> bool {
     const int o = coding_order(ux, uy);
-    return o < cur && (o >= slice_start || (o >> 8) == (cur >> 8));
+    if (o >= cur) return false;
+    if ((o >> 8) == (cur >> 8)) return true;
+    return o >= slice_start && ctu_tile[(size_t)(uy >> 4) * seq.ctus_w + (ux >> 4)] == my_tile;
   };
   auto is_intra = [&](int ux, int uy) -> bool { return (rec4[(size_t)uy * seq.uw + ux].flags & P4_INTRA) != 0; };
   IntraNeighbours nb = {0, 0, 0};

@@ -37,6 +37,8 @@ struct PackedPicture {
   bool inter_without_ref;           // an inter block with no reference at all (corrupt input)
   int64_t mc_ref_samples;           // luma+chroma samples predicted, counted once per reference used
   int next_ctu;
+  std::vector<int32_t> ctu_order;  // raster address -> position in coding order (-1: not added yet)
+  std::vector<int32_t> ctu_tile;   // raster address -> tile
   bool finished;
   std::string error;
 

@@ -33,7 +33,10 @@ class Syntax:
         if getattr(pic, "pred_weights", None) is not None:
             self.engine._check(lib.hevcrecon_syntax_set_pred_weights(self.h, C.addressof(pic.pred_weights)), "hevcrecon_syntax_set_pred_weights")
         ctus = pic.ctu_structs()
-        for a in range(pic.nctu):
+        order = range(pic.nctu)
+        if getattr(pic, "tiles", None) is not None:  # CTUs go in coding order (tile scan)
+            order = sorted(range(pic.nctu), key=lambda a: int(pic.tiles[a, 0]))
+        for a in order:
             self.engine._check(lib.hevcrecon_syntax_add_ctu(self.h, a, C.byref(ctus[a])), "hevcrecon_syntax_add_ctu")
         self.engine._check(lib.hevcrecon_syntax_finish(self.h, C.byref(pic.pic_params)), "hevcrecon_syntax_finish")
         self.poc = pic.poc

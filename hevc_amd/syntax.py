@@ -24,6 +24,7 @@ MAGIC_V1 = b"HVSYN1\0\0"  # older dumps: shorter picture parameters (abi.PIC_PAR
 PICT = 0x54434950
 SCAL = 0x4C414353  # optional record before a picture: the scaling lists it de-quantises with
 WPRD = 0x44525057  # optional record before a picture: its explicit prediction weights
+TILE = 0x454C4954  # optional record before a picture: (1 + coding-order address, tile index) of every CTU (tiles)
 SLST = 0x54534C53  # optional record before a picture: slice start address of every partition (several slices)
 PCMS = 0x534D4350  # optional record before a picture: PCM sample arrays of the CTUs that hold IPCM units
 _PCM_CTU_BYTES = 4 + (16 + 4 + 4) * abi.PARTS_PER_CTU * 2
@@ -59,6 +60,7 @@ class PictureSyntax:
         self.scaling = None  # abi.ScalingLists when the picture uses scaling lists
         self.pred_weights = None  # abi.PredWeights when the picture predicts with explicit weights
         self.slice_start = None  # (nctu, 256) uint32 when the picture has several slices
+        self.tiles = None        # (nctu, 2) int32 when the picture has tiles: 1 + coding-order address, tile index
         self.pcm = {}        # ctu address -> (y, cb, cr) int16 arrays, for the CTUs that hold IPCM units
         self.stage_md5 = None  # (3, 3) hex strings: [stage][component]
         self.planes = None   # optional [stage][component] 2-D uint16
@@ -100,6 +102,8 @@ class PictureSyntax:
                 for k in range(4):
                     s.sao_offset[c][k] = int(self.sao[i, c, 2 + k])
             s.slice_start = self.slice_start[i].ctypes.data if self.slice_start is not None else None
+            if self.tiles is not None:
+                s.coding_addr_plus1, s.tile_id = int(self.tiles[i, 0]), int(self.tiles[i, 1])
             for l in range(2):
                 s.mv[l] = ptr(a["mv%d" % l], i)
                 s.ref_idx[l] = ptr(a["ref_idx%d" % l], i)
@@ -148,7 +152,8 @@ def read_dump(path, max_pictures=None):
             pcm = {}
             weights = None
             slice_start = None
-            while tag in (SCAL, PCMS, WPRD, SLST):
+            tiles = None
+            while tag in (SCAL, PCMS, WPRD, SLST, TILE):
                 if tag == SCAL:
                     # the 16 bytes just read are the record's tag + 12 bytes of padding
                     scaling = abi.ScalingLists.from_buffer_copy(f.read(C.sizeof(abi.ScalingLists)))
@@ -156,6 +161,8 @@ def read_dump(path, max_pictures=None):
                     weights = abi.PredWeights.from_buffer_copy(f.read(C.sizeof(abi.PredWeights)))
                 elif tag == SLST:
                     slice_start = np.frombuffer(f.read(nctu * P * 4), dtype=np.uint32).reshape(nctu, P).copy()
+                elif tag == TILE:
+                    tiles = np.frombuffer(f.read(nctu * 8), dtype=np.int32).reshape(nctu, 2).copy()
                 else:
                     for _ in range(nctu):  # second header word: number of CTUs in the record
                         addr = struct.unpack("<i", f.read(4))[0]
@@ -170,6 +177,7 @@ def read_dump(path, max_pictures=None):
             pic.pcm = pcm
             pic.pred_weights = weights
             pic.slice_start = slice_start
+            pic.tiles = tiles
             raw = f.read(pp_size)
             C.memmove(C.addressof(pic.pic_params), raw, len(raw))
 
@@ -222,6 +230,10 @@ def strip_planes_and_compress(src, dst, preset=6):
             if tag == SCAL:  # optional scaling-list record: copied as it is
                 out.write(hdr)
                 out.write(f.read(C.sizeof(abi.ScalingLists)))
+                continue
+            if tag == TILE:
+                out.write(hdr)
+                out.write(f.read(nctu * 8))
                 continue
             if tag == SLST:
                 out.write(hdr)

@@ -115,6 +115,13 @@ typedef struct hevcrecon_ctu_syntax {
    * NULL: one slice.  The slices of a picture must agree in everything hevcrecon_pic_params carries, and filter
    * across their boundaries (slice_loop_filter_across_slices_enabled_flag = 1). */
   const uint32_t *slice_start;
+  /* Tiles (TComPicSym::getInverseCUOrderMap / getTileIdxMap, TLibCommon/TComPicSym.h): 1 + the CTU's address in
+   * coding order (tile scan), 0 = the same as its raster address; and the index of its tile.  CTUs are always added
+   * in coding order.  Intra prediction does not use neighbours of other CTUs that belong to another tile
+   * (bEnforceTileRestriction, TLibCommon/TComDataCU.cpp:1141-1589).  Tiles must filter across their boundaries
+   * (loop_filter_across_tiles_enabled_flag = 1). */
+  int32_t coding_addr_plus1;
+  int32_t tile_id;
 } hevcrecon_ctu_syntax;
 
 /* Scaling lists in effect for a picture: the TComScalingList that TDecTop::xDecodeSlice has resolved from

@@ -227,6 +227,7 @@ struct Bridge {
         for (int r = 0; same && !a->isIntra() && r < a->getNumRefIdx(RefPicList(l)); r++)
           same = a->getRefPic(RefPicList(l), r) == b->getRefPic(RefPicList(l), r);
       }
+      same = same && a->getPPS()->getLoopFilterAcrossTilesEnabledFlag();
       if (!same) {
         fprintf(stderr, "hm_bridge: the slices of POC %d differ in their slice-level parameters or do not filter across slice boundaries\n", a->getPOC());
         exit(EXIT_FAILURE);
@@ -239,6 +240,8 @@ struct Bridge {
     memset(&cs, 0, sizeof(cs));
     for (int i = 0; i < HEVCRECON_PARTS_PER_CTU; i++) slicebuf[i] = cu->getSliceStartCU(i);
     cs.slice_start = slicebuf;
+    cs.coding_addr_plus1 = (int32_t)pic->getPicSym()->getInverseCUOrderMap(addr) + 1;
+    cs.tile_id = (int32_t)pic->getPicSym()->getTileIdxMap(addr);
     cs.depth = cu->getDepth();
     cs.pred_mode = (const int8_t *)cu->getPredictionMode();
     cs.part_size = (const int8_t *)cu->getPartitionSize();
@@ -330,6 +333,20 @@ struct Bridge {
     for (int a = 0; a < nctu; a++)
       fill_ctu(pic, a, pp, cs[a], &refbuf[a * 2 * HEVCRECON_PARTS_PER_CTU], &slicebuf[a * HEVCRECON_PARTS_PER_CTU]);
     const int P = HEVCRECON_PARTS_PER_CTU;
+    {  // optional record in front of the picture: coding order and tile of every CTU, when there are tiles
+      bool any = false;
+      std::vector<int32_t> tl(2 * nctu);
+      for (int a = 0; a < nctu; a++) {
+        tl[2 * a] = cs[a].coding_addr_plus1;
+        tl[2 * a + 1] = cs[a].tile_id;
+        any = any || cs[a].tile_id != 0;
+      }
+      if (any) {
+        int32_t thdr[4] = {0x454C4954 /* "TILE" */, nctu, 0, 0};
+        put(thdr, 4);
+        put(&tl[0], tl.size());
+      }
+    }
     {  // optional record in front of the picture: slice start addresses, when there is more than one slice
       bool any = false;
       for (size_t i = 0; i < slicebuf.size() && !any; i++) any = slicebuf[i] != 0;
@@ -421,7 +438,8 @@ struct Bridge {
     hevcrecon_pred_weights pw;
     if (fill_weights(pic, pw) && api.syntax_set_pred_weights(syn, &pw)) fail("hevcrecon_syntax_set_pred_weights");
     int nctu = pic->getNumCUsInFrame();
-    for (int a = 0; a < nctu; a++) {
+    for (int i = 0; i < nctu; i++) {
+      const int a = (int)pic->getPicSym()->getCUOrderMap(i);  // coding order (tile scan)
       hevcrecon_ctu_syntax cs;
       int8_t refbuf[2 * HEVCRECON_PARTS_PER_CTU];
       uint32_t slicebuf[HEVCRECON_PARTS_PER_CTU];

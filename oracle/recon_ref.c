@@ -21,6 +21,7 @@
 
 #define MAXPICS 4096
 #define NPART 256
+#define MAXCTUS 16384 /* 8192 x 8192 luma samples */
 
 typedef struct {
   int16_t *p[3];
@@ -38,6 +39,7 @@ typedef struct hevcref_ctx {
   const hevcrecon_ctu_syntax *ctus;
   int use_sl;                 /* de-quantise with the scaling lists below */
   hevcrecon_scaling_lists sl;
+  int ctu_order[MAXCTUS];     /* raster address -> position in coding order (tile scan) */
   int use_wp;                 /* predict with the explicit weights below */
   hevcrecon_pred_weights wp;
   int16_t *rec[3];
@@ -439,9 +441,9 @@ static void inter_residual(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu
 
 /* ---------------------------------------------------------------- intra ------------ */
 
-/* Position of a 4x4 unit in coding order: CTUs in raster order, z-order inside a CTU. */
+/* Position of a 4x4 unit in coding order: CTUs in raster order or tile scan, z-order inside a CTU. */
 static inline int coding_order(const hevcref_ctx *c, int ux, int uy) {
-  return ((uy >> 4) * c->ctus_w + (ux >> 4)) * NPART + c->raster_to_z[uy & 15][ux & 15];
+  return c->ctu_order[(uy >> 4) * c->ctus_w + (ux >> 4)] * NPART + c->raster_to_z[uy & 15][ux & 15];
 }
 
 /* Reference-sample array ref[0..4n]: index 2n is the corner, 2n-1-j is the left column going down,
@@ -451,7 +453,7 @@ static inline int coding_order(const hevcref_ctx *c, int ux, int uy) {
  * TComDataCU::getPULeft/Above/AboveLeft/AboveRightAdi/BelowLeftAdi (TLibCommon/TComDataCU.cpp:1141-1589)
  * for one slice, one tile, unconstrained intra: a 4x4 unit is available iff it lies inside the
  * picture and precedes the current block in coding order. */
-static void build_intra_refs(const hevcref_ctx *c, int comp, int x0, int y0, int n, int slice_start, int *ref) {
+static void build_intra_refs(const hevcref_ctx *c, int comp, int x0, int y0, int n, int slice_start, int tile_id, int *ref) {
   int sh = comp ? 1 : 0, us = 4 >> sh; /* unit size in samples of this plane */
   int pw = plane_w(c, comp), ph = plane_h(c, comp);
   const int16_t *p = c->rec[comp];
@@ -478,7 +480,10 @@ static void build_intra_refs(const hevcref_ctx *c, int comp, int x0, int y0, int
       /* neighbours in another CTU must belong to the block's slice (bEnforceSliceRestriction in TComDataCU::getPULeft,
        * getPUAbove, getPUAboveLeft, getPUAboveRightAdi, getPUBelowLeftAdi, TLibCommon/TComDataCU.cpp:1141-1589; no
        * such check for neighbours inside the CTU) */
-      if (ok && (o >> 8) != (cur >> 8)) ok = o >= slice_start;
+      if (ok && (o >> 8) != (cur >> 8)) {
+        const hevcrecon_ctu_syntax *nc = &c->ctus[(((sy << sh) >> 6)) * c->ctus_w + ((sx << sh) >> 6)];
+        ok = o >= slice_start && nc->tile_id == tile_id; /* ... and to its tile (bEnforceTileRestriction) */
+      }
     }
     if (ok && c->pp->constrained_intra_pred) { /* TComPattern::is*Available with constrained intra prediction */
       PartRef nb = part_at(c, sx << sh, sy << sh);
@@ -641,7 +646,7 @@ static void intra_block(hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int zcu
                         int log2, int mode) {
   int n = 1 << log2;
   int ref[4 * 32 + 1], fref[4 * 32 + 1];
-  build_intra_refs(c, comp, x0, y0, n, ctu->slice_start ? (int)ctu->slice_start[z] : 0, ref);
+  build_intra_refs(c, comp, x0, y0, n, ctu->slice_start ? (int)ctu->slice_start[z] : 0, ctu->tile_id, ref);
   const int *use = ref;
   if (comp == 0 && mode != 1) { /* TComPattern::getPredictorPtr, TLibCommon/TComPattern.cpp:627-651 */
     static const int thr[4] = {10, 7, 1, 0};
@@ -981,7 +986,24 @@ int hevcref_reconstruct(hevcref_ctx *c, const hevcrecon_pic_params *pp, const he
   c->pp = pp;
   c->ctus = ctus;
   for (int i = 0; i < 3; i++) c->rec[i] = c->stage[1][i];
-  for (int a = 0; a < nctu; a++) decompress_cu(c, &ctus[a], (a % c->ctus_w) * 64, (a / c->ctus_w) * 64, 0, 0);
+  /* CTUs in coding order: raster, or tile scan when the caller numbers them */
+  if (nctu > MAXCTUS) return 1;
+  int *by_order = (int *)malloc(sizeof(int) * nctu);
+  for (int a = 0; a < nctu; a++) by_order[a] = -1;
+  for (int a = 0; a < nctu; a++) {
+    int o = ctus[a].coding_addr_plus1 ? ctus[a].coding_addr_plus1 - 1 : a;
+    if (o < 0 || o >= nctu || by_order[o] >= 0) {
+      free(by_order);
+      return 1;
+    }
+    by_order[o] = a;
+    c->ctu_order[a] = o;
+  }
+  for (int o = 0; o < nctu; o++) {
+    int a = by_order[o];
+    decompress_cu(c, &ctus[a], (a % c->ctus_w) * 64, (a / c->ctus_w) * 64, 0, 0);
+  }
+  free(by_order);
   memcpy(c->stage[0][0], c->rec[0], sizeof(int16_t) * c->w * c->h);
   memcpy(c->stage[0][1], c->rec[1], sizeof(int16_t) * c->cw * c->ch);
   memcpy(c->stage[0][2], c->rec[2], sizeof(int16_t) * c->cw * c->ch);

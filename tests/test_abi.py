@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header():
     assert C.sizeof(abi.SeqParams) == 16 * 4
     assert C.sizeof(abi.PicParams) == (13 + 2 * 16 * 2 + 8) * 4
-    assert C.sizeof(abi.CtuSyntax) == 26 * 8 + (3 + 3 + 12) * 4
+    assert C.sizeof(abi.CtuSyntax) == 26 * 8 + (3 + 3 + 12 + 2) * 4
 
 
 def test_missing_library_fails_loudly(tmp_path):

@@ -20,7 +20,7 @@ def emu_lib():
     return abi.load_library(EMU)
 
 
-@pytest.mark.parametrize("stream,npics", [("randomaccess_he10", 3), ("lowdelay_P_main", 2), ("scalinglist", 2), ("pcm", 1), ("pcmlf", 2), ("wpp", 3), ("wpb", 3), ("cip", 2), ("bd12", 3), ("slices", 2)])
+@pytest.mark.parametrize("stream,npics", [("randomaccess_he10", 3), ("lowdelay_P_main", 2), ("scalinglist", 2), ("pcm", 1), ("pcmlf", 2), ("wpp", 3), ("wpb", 3), ("cip", 2), ("bd12", 3), ("slices", 2), ("tiles", 2)])
 def test_emulated_engine_matches_oracle(emu_lib, stream, npics):
     seq = load_golden(stream + "_416x240", npics)
     eng = engine.Engine(seq.seq_params, lib=emu_lib)

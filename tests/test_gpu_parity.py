@@ -127,7 +127,7 @@ def test_all_stages_md5_exact_1080p(stream):
     eng.close()
 
 
-@pytest.mark.parametrize("bits,npics", [("lowdelay_P_main_240", 9), ("randomaccess_he10_240", 9), ("scalinglist_240", 9), ("lossless_240", 6), ("pcm_240", 5), ("pcmlf_240", 4), ("wpp_240", 9), ("wpb_240", 9), ("cip_240", 6), ("bd12_240", 5), ("slices_240", 5), ("randomaccess_main_1080", 60),
+@pytest.mark.parametrize("bits,npics", [("lowdelay_P_main_240", 9), ("randomaccess_he10_240", 9), ("scalinglist_240", 9), ("lossless_240", 6), ("pcm_240", 5), ("pcmlf_240", 4), ("wpp_240", 9), ("wpb_240", 9), ("cip_240", 6), ("bd12_240", 5), ("slices_240", 5), ("tiles_240", 5), ("randomaccess_main_1080", 60),
                                         # encoder option sweep (tools/make_fixtures.sh): per-CU QP changes + chroma QP offsets + deblocking
                                         # offsets; QP 22 with picture-based SAO; QP 45 without deblocking; transform trees of depth 3
                                         # without AMP / SAO / transform skip; low-delay B

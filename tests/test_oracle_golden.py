@@ -160,3 +160,20 @@ def test_slice_starts_are_what_makes_the_slices_stream_match():
     ref.reconstruct(pic)
     luma = ref.download(2, pic.pic_id)[0]
     assert syntax.plane_md5(luma, seq.seq_params.bit_depth_luma) != pic.stage_md5[2][0]
+
+
+def test_tile_ids_are_what_makes_the_tiles_stream_match():
+    """Negative control for the tiles fixture: with every CTU in one tile (coding order kept), its first picture
+    must NOT match."""
+    import copy
+
+    seq = load_golden("tiles_416x240", 1)
+    pic = copy.copy(seq.pictures[0])
+    assert pic.tiles is not None and len(set(pic.tiles[:, 1].tolist())) == 6
+    pic.tiles = pic.tiles.copy()
+    pic.tiles[:, 1] = 0
+    pic._keep = None
+    ref = RefModel(seq.seq_params)
+    ref.reconstruct(pic)
+    luma = ref.download(2, pic.pic_id)[0]
+    assert syntax.plane_md5(luma, seq.seq_params.bit_depth_luma) != pic.stage_md5[2][0]

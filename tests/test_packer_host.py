@@ -64,7 +64,7 @@ def test_ctu_order_is_enforced():
     syn = engine.detached_syntax(seq.seq_params)
     ctus = pic.ctu_structs()
     assert lib.hevcrecon_syntax_begin(syn.h) == 0
-    assert lib.hevcrecon_syntax_add_ctu(syn.h, 1, C.byref(ctus[1])) != 0  # CTU 0 first
+    assert lib.hevcrecon_syntax_add_ctu(syn.h, 1, C.byref(ctus[1])) != 0  # CTU 0 first (coding order = raster order without tiles)
     assert lib.hevcrecon_syntax_begin(syn.h) == 0
     assert lib.hevcrecon_syntax_add_ctu(syn.h, 0, C.byref(ctus[0])) == 0
     assert lib.hevcrecon_syntax_finish(syn.h, C.byref(pic.pic_params)) != 0  # not all CTUs added
