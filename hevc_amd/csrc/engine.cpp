@@ -13,6 +13,7 @@
 #endif
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/hevcrecon.h"
@@ -29,6 +30,37 @@ const int kRing = 16;
 // 1 stream 53 k, 3 streams 64 k, 4 streams 65 k, 8 streams 44 k frames/s; a kernel reading the pinned buffers
 // itself reached only 10 GB/s over the link).
 const int kCopyStreams = 3;
+
+// The copy streams belong to the device, not to a context: several contexts on one GPU (each with a kernel stream of
+// its own) share them, so that the process stays near its four hardware queues.
+struct SharedCopyStreams {
+  hipStream_t s[kCopyStreams];
+  int refs;
+};
+SharedCopyStreams g_copy[64];
+std::mutex g_copy_mutex;
+
+bool acquire_copy_streams(int device, hipStream_t out[kCopyStreams]) {
+  if (device < 0 || device >= 64) return false;
+  std::lock_guard<std::mutex> lock(g_copy_mutex);
+  SharedCopyStreams &g = g_copy[device];
+  if (g.refs == 0)
+    for (int i = 0; i < kCopyStreams; i++)
+      if (hipStreamCreate(&g.s[i]) != hipSuccess) {
+        for (int k = 0; k < i; k++) hipStreamDestroy(g.s[k]);
+        return false;
+      }
+  g.refs++;
+  for (int i = 0; i < kCopyStreams; i++) out[i] = g.s[i];
+  return true;
+}
+
+void release_copy_streams(int device) {
+  std::lock_guard<std::mutex> lock(g_copy_mutex);
+  SharedCopyStreams &g = g_copy[device];
+  if (g.refs > 0 && --g.refs == 0)
+    for (int i = 0; i < kCopyStreams; i++) hipStreamDestroy(g.s[i]);
+}
 
 struct DevPicture {
   void *base = nullptr;
@@ -47,6 +79,7 @@ struct hevcrecon_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream[kCopyStreams] = {};  // syntax uploads run beside the reconstruction kernels
+  bool have_copy_streams = false;
   int copy_rr = 0;
   bool have_seq = false;
   hevcrecon_seq_params sp;
@@ -271,7 +304,8 @@ extern "C" int hevcrecon_create(hevcrecon_ctx **out, int device) {
   std::memset(c->launches, 0, sizeof(c->launches));
   std::memset(c->ring_used, 0, sizeof(c->ring_used));
   bool ok = hipStreamCreate(&c->stream) == hipSuccess;
-  for (int i = 0; ok && i < kCopyStreams; i++) ok = hipStreamCreate(&c->copy_stream[i]) == hipSuccess;
+  ok = ok && acquire_copy_streams(device, c->copy_stream);
+  c->have_copy_streams = ok;
   ok = ok && hipHostMalloc((void **)&c->jobs_host, sizeof(PicJob) * HR_MAX_BATCH * kRing) == hipSuccess;
   ok = ok && hipMalloc((void **)&c->jobs_dev, sizeof(PicJob) * HR_MAX_BATCH * kRing) == hipSuccess;
 
@@ -280,6 +314,7 @@ extern "C" int hevcrecon_create(hevcrecon_ctx **out, int device) {
   for (int i = 0; ok && i < kRing; i++) ok = hipEventCreateWithFlags(&c->batch_ev[i], hipEventDisableTiming) == hipSuccess;
   for (int i = 0; ok && i < kRing * kCopyStreams; i++) ok = hipEventCreateWithFlags(&c->copy_ev[i], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
+    if (c->have_copy_streams) release_copy_streams(device);
     delete c;
     return 3;
   }
@@ -311,8 +346,10 @@ extern "C" void hevcrecon_destroy(hevcrecon_ctx *c) {
   if (c->error_flag_dev) hipFree(c->error_flag_dev);
   if (c->dl_host) hipHostFree(c->dl_host);
   hipStreamDestroy(c->stream);
-  for (int i = 0; i < kCopyStreams; i++)
-    if (c->copy_stream[i]) hipStreamDestroy(c->copy_stream[i]);
+  if (c->have_copy_streams) {
+    for (int i = 0; i < kCopyStreams; i++) hipStreamSynchronize(c->copy_stream[i]);
+    release_copy_streams(c->device);
+  }
   delete c;
 }
 

@@ -14,9 +14,9 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tra
 cp $O/trace/*/*kernel_stats.csv $O/kernel_stats.csv
 rm -rf $O/trace
 cd $R
-bash tools/pmc_passes.sh 128
+bash tools/pmc_passes.sh 128   # bench defaults: 128 streams over 2 contexts = 64 pictures per launch
 python3 tools/pmc_summary.py gpurun_out/pmc > $O/pmc_summary.txt
-python3 tools/pmc_traffic.py gpurun_out/pmc 128 randomaccess_main_1920x1080 > $O/hbm_traffic.json
+python3 tools/pmc_traffic.py gpurun_out/pmc 64 randomaccess_main_1920x1080 > $O/hbm_traffic.json
 rm -rf gpurun_out/pmc/p*/
 cp $O/hbm_traffic.json profiles/hbm_traffic.json  # the bench line below reads its roofline.traffic from there
 timeout -k 10 500 python3 -u bench.py > $O/bench.log 2>&1
