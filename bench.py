@@ -255,9 +255,9 @@ def main():
         pass
 
     # ---- syntax hand-over (untimed for `value`): the packed pictures cross the host link again ----
-    # Two steps in which every picture is marked for upload before its batch is submitted: the engine fetches a
-    # batch's pictures from their pinned buffers with one kernel on its copy stream, beside the previous batch's
-    # kernels, and expands the run-length coded records.  (Packing itself, host work of the decoder, is not repeated.)
+    # Two steps in which every picture is marked for upload before its batch is submitted: the engine copies a
+    # batch's pictures from their pinned buffers on its copy streams, beside the previous batch's kernels, and
+    # expands the run-length coded records.  (Packing itself, host work of the decoder, is not repeated.)
     handover = None
     if not args.no_handover:
         up_bytes = sum(syns[t][0].stats()[29] for t in range(npic))

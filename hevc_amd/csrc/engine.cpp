@@ -101,7 +101,7 @@ struct hevcrecon_ctx {
   hipEvent_t batch_ev[kRing];
   int64_t batch_no = 0;
   // Cross-stream waits are expensive, and both streams run in order: the main stream waits for an upload only
-  // when it is newer than the newest one it has already waited for, and the copy stream likewise for batches.
+  // when it is newer than the newest one it has already waited for, and the copy streams likewise for batches.
   int64_t upload_no = 0, upload_waited = -1, upload_synced = -1, batch_waited = -1;
   hipEvent_t copy_ev[kRing * kCopyStreams];  // recorded on the copy streams when the main stream has to wait for uploads
   int copy_ev_pos = 0;
@@ -129,7 +129,7 @@ struct hevcrecon_syntax {
   size_t upload_bytes = 0, off_runs = 0, off_runoff = 0;
   bool expanded = false;       // rec4 has been expanded from the uploaded runs
   int64_t last_batch = -1;     // last batch whose kernels read the device copy
-  int64_t upload_seq = -1;     // position of the last upload in the copy stream
+  int64_t upload_seq = -1;     // number of the batch of copies that carried the last upload
   size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_mct[3] = {0, 0, 0}, off_mcb = 0, off_scal = 0, off_wp = 0;
   bool uploaded = false;
   std::string err;
