@@ -108,6 +108,8 @@ struct hevcrecon_ctx {
   int ring_pos = 0;
   int32_t *error_flag_dev = nullptr;
   void *dl_host = nullptr;  // pinned staging for downloads / uploads
+  void *out_dev = nullptr;  // a picture in file format (hevcrecon_picture_download_file)
+  size_t out_cap = 0;
   size_t dl_cap = 0;
   bool profiling = false;
   std::vector<Interval> intervals;
@@ -345,6 +347,7 @@ extern "C" void hevcrecon_destroy(hevcrecon_ctx *c) {
 
   if (c->error_flag_dev) hipFree(c->error_flag_dev);
   if (c->dl_host) hipHostFree(c->dl_host);
+  if (c->out_dev) hipFree(c->out_dev);
   hipStreamDestroy(c->stream);
   if (c->have_copy_streams) {
     for (int i = 0; i < kCopyStreams; i++) hipStreamSynchronize(c->copy_stream[i]);
@@ -875,6 +878,36 @@ extern "C" int hevcrecon_picture_download(hevcrecon_ctx *c, int pic_id, int16_t 
   if (pic_id < 0 || pic_id >= (int)c->pics.size() || !c->pics[pic_id].valid) return fail(c, "picture is not resident");
   HIPCHK(c, hipSetDevice(c->device));
   return download_planes(c, c->pics[pic_id], y, cb, cr, stride_y, stride_c);
+}
+
+extern "C" int hevcrecon_picture_download_file(hevcrecon_ctx *c, int pic_id, int file_bit_depth_luma, int file_bit_depth_chroma, int width,
+                                               int height, void *out, int64_t out_bytes) {
+  if (!c || !out) return 1;
+  if (pic_id < 0 || pic_id >= (int)c->pics.size() || !c->pics[pic_id].valid) return fail(c, "picture is not resident");
+  const SeqInfo &s = c->si;
+  if (width <= 0 || height <= 0 || width > s.w || height > s.h || (width & 1) || (height & 1) || file_bit_depth_luma < 8 ||
+      file_bit_depth_luma > 16 || file_bit_depth_chroma < 8 || file_bit_depth_chroma > 16)
+    return fail(c, "bad output size or file bit depth");
+  const bool wide = file_bit_depth_luma > 8 || file_bit_depth_chroma > 8;
+  const size_t need = ((size_t)width * height + 2 * (size_t)(width / 2) * (height / 2)) * (wide ? 2 : 1);
+  if (out_bytes < (int64_t)need) return fail(c, "output buffer too small");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->out_cap < need) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->out_dev) hipFree(c->out_dev);
+    c->out_dev = nullptr;
+    c->out_cap = 0;
+    HIPCHK(c, hipMalloc(&c->out_dev, need));
+    c->out_cap = need;
+  }
+  if (ensure_staging(c, need)) return 1;
+  const void *planes[3] = {c->pics[pic_id].p[0], c->pics[pic_id].p[1], c->pics[pic_id].p[2]};
+  hr_launch_output(planes, c->out_dev, s, width, height, file_bit_depth_luma, file_bit_depth_chroma, wide, c->stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->dl_host, c->out_dev, need, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(out, c->dl_host, need);
+  return 0;
 }
 
 extern "C" int hevcrecon_debug_keep_stages(hevcrecon_ctx *c, int on) {

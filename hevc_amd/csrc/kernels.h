@@ -9,4 +9,10 @@
 // records of the pictures whose need_expand is set.
 void hr_launch(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t stream, int arg, int arg2);
 
+// Converts picture planes to the bytes TVideoIOYuv::write puts into a file: width x height samples of each plane
+// (chroma: half of each), `file_bd` bits deep (scaled from the internal depth with rounding and clipping, or shifted
+// up), one byte per sample or two (little endian) when wide is set.  planes / dst: device memory.
+void hr_launch_output(const void *const planes[3], void *dst, const SeqInfo &s, int width, int height, int file_bd_y, int file_bd_c,
+                      bool wide, hipStream_t stream);
+
 #endif

@@ -1817,6 +1817,27 @@ __global__ __launch_bounds__(256) void k_expand(const PicJob *jobs, SeqInfo s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_output: a picture as the reference's file writer stores it (TVideoIOYuv::write / writePlane / scalePlane /
+// invScalePlane, TLibVideoIO/TVideoIOYuv.cpp:62-126,305-340,422-489): planes back to back, rows without padding,
+// samples scaled from the internal to the file bit depth (down: rounded and clipped to the file range; up: shifted),
+// one byte per sample, or two (low byte first) when either file depth exceeds 8.  One lane per sample.
+// ------------------------------------------------------------------------------------------------
+template <typename pel_t, bool WIDE>
+__global__ __launch_bounds__(256) void k_output(const pel_t *src, int stride, uint8_t *dst, int width, int height, int shift, int maxv) {
+  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+  if (x >= width || y >= height) return;
+  int v = src[(size_t)y * stride + x];
+  if (shift > 0)
+    v = clip3i(0, maxv, (v + (1 << (shift - 1))) >> shift);
+  else
+    v = v << (-shift);
+  if (WIDE)
+    ((uint16_t *)dst)[(size_t)y * width + x] = (uint16_t)v;
+  else
+    dst[(size_t)y * width + x] = (uint8_t)v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 #define LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
@@ -1868,6 +1889,26 @@ static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, 
       break;
     default:
       break;
+  }
+}
+
+void hr_launch_output(const void *const planes[3], void *dst, const SeqInfo &s, int width, int height, int file_bd_y, int file_bd_c,
+                      bool wide, hipStream_t st) {
+  uint8_t *out = (uint8_t *)dst;
+  const int ws = wide ? 2 : 1;
+  for (int k = 0; k < 3; k++) {
+    const int w = k ? width / 2 : width, h = k ? height / 2 : height, stride = k ? s.stride_c : s.stride_y;
+    const int bd = k ? s.bd_c : s.bd_y, fbd = k ? file_bd_c : file_bd_y;
+    const int shift = bd - fbd, maxv = (1 << fbd) - 1;
+    const dim3 g((w + 255) / 256, h);
+    if (s.bd_y <= 8 && s.bd_c <= 8) {
+      if (wide) LAUNCH((k_output<uint8_t, true>), g, dim3(256), st, (const uint8_t *)planes[k], stride, out, w, h, shift, maxv);
+      else LAUNCH((k_output<uint8_t, false>), g, dim3(256), st, (const uint8_t *)planes[k], stride, out, w, h, shift, maxv);
+    } else {
+      if (wide) LAUNCH((k_output<uint16_t, true>), g, dim3(256), st, (const uint16_t *)planes[k], stride, out, w, h, shift, maxv);
+      else LAUNCH((k_output<uint16_t, false>), g, dim3(256), st, (const uint16_t *)planes[k], stride, out, w, h, shift, maxv);
+    }
+    out += (size_t)w * h * ws;
   }
 }
 

@@ -119,6 +119,15 @@ class Engine:
                                                         self.w, self.w // 2), "hevcrecon_picture_download")
         return p
 
+    def download_file(self, pic_id, file_bit_depths, width=None, height=None):
+        """The picture as bytes of the reference decoder's output file (see hevcrecon_picture_download_file)."""
+        w, h = width or self.w, height or self.h
+        wide = max(file_bit_depths) > 8
+        out = np.empty((w * h + 2 * (w // 2) * (h // 2)) * (2 if wide else 1), np.uint8)
+        self._check(self.lib.hevcrecon_picture_download_file(self.ctx, pic_id, file_bit_depths[0], file_bit_depths[1], w, h,
+                                                             out.ctypes.data, out.nbytes), "hevcrecon_picture_download_file")
+        return out
+
     def keep_stages(self, on=True):
         self._check(self.lib.hevcrecon_debug_keep_stages(self.ctx, 1 if on else 0), "hevcrecon_debug_keep_stages")
 

@@ -236,6 +236,15 @@ int hevcrecon_reconstruct_batch(hevcrecon_ctx *ctx, int n, hevcrecon_syntax *con
 int hevcrecon_picture_download(hevcrecon_ctx *ctx, int pic_id, int16_t *y, int16_t *cb, int16_t *cr,
                                int stride_y, int stride_c);
 
+/* Replaces TVideoIOYuv::write (TLibVideoIO/TVideoIOYuv.cpp:422-489) for a picture that is resident on the device:
+ * `out` receives exactly the bytes the reference writes to its output file — Y, Cb, Cr planes of width x height
+ * luma samples (the picture size minus the cropping the caller passes to write(); like the reference, the window
+ * starts at the top left sample), scaled from the internal to the file bit depth (scalePlane / invScalePlane,
+ * :62-126), one byte per sample, or two (low byte first) when either file depth exceeds 8 (writePlane, :305-340).
+ * Only those bytes cross the host link.  Blocks until done. */
+int hevcrecon_picture_download_file(hevcrecon_ctx *ctx, int pic_id, int file_bit_depth_luma, int file_bit_depth_chroma,
+                                    int width, int height, void *out, int64_t out_bytes);
+
 /* Stage-level parity checks: after hevcrecon_debug_keep_stages(ctx, 1) every reconstruct call also keeps a
  * copy of its first picture before deblocking (stage 0) and after deblocking, before SAO (stage 1). */
 int hevcrecon_debug_keep_stages(hevcrecon_ctx *ctx, int on);

@@ -39,3 +39,25 @@ def test_emulated_engine_matches_oracle(emu_lib, stream, npics):
     syn.close()
     eng.close()
     ref.close()
+
+
+@pytest.mark.parametrize("stream,depth", [("randomaccess_he10", 8), ("lowdelay_P_main", 10)])
+def test_emulated_output_file_format(emu_lib, stream, depth):
+    """hevcrecon_picture_download_file against the bytes the reference decoder wrote with -d <depth> (digest per frame
+    of its output file, display order): scaling down with rounding and clipping, and scaling up."""
+    import hashlib
+    import json
+
+    from conftest import GOLDEN
+
+    want = json.load(open(os.path.join(GOLDEN, "output_md5.json")))["%s_240_d%d" % (stream, depth)]
+    seq = load_golden(stream + "_416x240", 3)
+    eng = engine.Engine(seq.seq_params, lib=emu_lib)
+    syn = eng.new_syntax()
+    for pic in seq.pictures:
+        syn.pack(pic)
+        eng.reconstruct(syn, pic.pic_id)
+        data = eng.download_file(pic.pic_id, (depth, depth))
+        assert hashlib.md5(data.tobytes()).hexdigest() == want[pic.poc], pic.poc
+    syn.close()
+    eng.close()

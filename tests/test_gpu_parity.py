@@ -81,6 +81,27 @@ def test_errors_are_reported_not_crashed():
     eng.close()
 
 
+@pytest.mark.parametrize("stream,depth", [("randomaccess_he10", 8), ("randomaccess_he10", 10), ("lowdelay_P_main", 10), ("bd12", 8)])
+def test_output_file_format(stream, depth):
+    """hevcrecon_picture_download_file against the bytes the reference decoder wrote with -d <depth> (digest per frame
+    of its output file, display order)."""
+    import hashlib
+
+    want = json.load(open(os.path.join(GOLDEN, "output_md5.json")))["%s_240_d%d" % (stream, depth)]
+    seq = load_golden(stream + "_416x240")
+    eng = engine.Engine(seq.seq_params)
+    syn = eng.new_syntax()
+    for pic in seq.pictures:
+        syn.pack(pic)
+        eng.reconstruct(syn, pic.pic_id)
+        data = eng.download_file(pic.pic_id, (depth, depth))
+        assert hashlib.md5(data.tobytes()).hexdigest() == want[pic.poc], pic.poc
+    with pytest.raises(engine.EngineError):
+        eng.download_file(seq.pictures[0].pic_id, (depth, depth), width=4096)
+    syn.close()
+    eng.close()
+
+
 def test_packed_pictures_can_be_uploaded_again():
     """hevcrecon_syntax_upload: a packed picture copied to the device a second time (runs expanded again, while
     other pictures are being reconstructed) gives the same picture; an unfinished one is refused."""

@@ -52,6 +52,23 @@ D="$root/oracle/_ref/TAppDecoderBridge"
 for s in lowdelay_P_main_240 randomaccess_main_240 randomaccess_he10_240 intra_main_240 scalinglist_240 lossless_240 pcm_240 pcmlf_240 wpp_240 wpb_240 cip_240 bd12_240 slices_240 tiles_240 ra_main_1080 ra_he10_1080 intra_main_1080; do
   HEVCRECON_MODE=dump HEVCRECON_DUMP=$s.syn $D -b $s.bin > $s.dec.log
 done
+# the reference decoder's output files at other bit depths than the internal one (digest per frame, display order)
+R="$root/oracle/_ref/TAppDecoder"
+$R -b randomaccess_he10_240.bin -o he10_d8.yuv -d 8 > /dev/null
+$R -b randomaccess_he10_240.bin -o he10_d10.yuv -d 10 > /dev/null
+$R -b lowdelay_P_main_240.bin -o ldp_d10.yuv -d 10 > /dev/null
+$R -b bd12_240.bin -o bd12_d8.yuv -d 8 > /dev/null
+cd "$root" && python - <<'PY'
+import hashlib
+out = {}
+for name, f, ws in (("randomaccess_he10_240_d8", "work/he10_d8.yuv", 1), ("randomaccess_he10_240_d10", "work/he10_d10.yuv", 2),
+                    ("lowdelay_P_main_240_d10", "work/ldp_d10.yuv", 2), ("bd12_240_d8", "work/bd12_d8.yuv", 1)):
+    data = open(f, "rb").read()
+    fb = 416 * 240 * 3 // 2 * ws
+    out[name] = [hashlib.md5(data[i * fb:(i + 1) * fb]).hexdigest() for i in range(len(data) // fb)]
+import json
+json.dump(out, open("tests/golden/output_md5.json", "w"), indent=0)
+PY
 cd "$root" && python - <<'PY'
 import json, re, shutil
 from hevc_amd import syntax
