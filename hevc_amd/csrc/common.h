@@ -175,6 +175,14 @@ struct PicJob {
   int32_t *error_flag;
 };
 
+#define HR_MD5_MAX_PICTURES 4096  // pictures per hevcrecon_picture_md5_batch call
+
+// One plane to digest: k_md5 hashes rows x row_bytes bytes (row_bytes a multiple of 4), rows stride_bytes apart.
+struct Md5Plane {
+  const void *base;
+  uint32_t row_bytes, rows, stride_bytes, pad;
+};
+
 // Kernel classes for the per-kernel timers (hevcrecon_profile_read).
 // K_INTER is also the launch kind of all four inter kernels; its timer slot holds the 64x64 tile kernel.
 // K_OTHER holds k_expand.

@@ -910,6 +910,46 @@ extern "C" int hevcrecon_picture_download_file(hevcrecon_ctx *c, int pic_id, int
   return 0;
 }
 
+extern "C" int hevcrecon_picture_md5_batch(hevcrecon_ctx *c, int n, const int *pic_ids, uint8_t *digests) {
+  if (!c || !pic_ids || !digests) return 1;
+  if (n <= 0 || n > HR_MD5_MAX_PICTURES) return fail(c, "number of pictures to digest out of range");
+  for (int i = 0; i < n; i++)
+    if (pic_ids[i] < 0 || pic_ids[i] >= (int)c->pics.size() || !c->pics[pic_ids[i]].valid) return fail(c, "picture is not resident");
+  HIPCHK(c, hipSetDevice(c->device));
+  const SeqInfo &s = c->si;
+  const size_t pb = c->pel_bytes;
+  const size_t desc_bytes = align_up(sizeof(Md5Plane) * 3 * n, 256), dig_bytes = (size_t)48 * n;
+  if (ensure_staging(c, desc_bytes + dig_bytes)) return 1;
+  if (c->out_cap < desc_bytes + dig_bytes) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->out_dev) hipFree(c->out_dev);
+    c->out_dev = nullptr;
+    c->out_cap = 0;
+    HIPCHK(c, hipMalloc(&c->out_dev, desc_bytes + dig_bytes));
+    c->out_cap = desc_bytes + dig_bytes;
+  }
+  // lanes of a wave should run equally long: all luma planes first, then the chroma planes
+  Md5Plane *d = (Md5Plane *)c->dl_host;
+  for (int i = 0; i < n; i++) {
+    const DevPicture &p = c->pics[pic_ids[i]];
+    d[i] = Md5Plane{p.p[0], (uint32_t)(s.w * pb), (uint32_t)s.h, (uint32_t)(s.stride_y * pb), 0};
+    d[n + 2 * i] = Md5Plane{p.p[1], (uint32_t)(s.cw * pb), (uint32_t)s.ch, (uint32_t)(s.stride_c * pb), 0};
+    d[n + 2 * i + 1] = Md5Plane{p.p[2], (uint32_t)(s.cw * pb), (uint32_t)s.ch, (uint32_t)(s.stride_c * pb), 0};
+  }
+  uint8_t *dig_dev = (uint8_t *)c->out_dev + desc_bytes;
+  HIPCHK(c, hipMemcpyAsync(c->out_dev, d, sizeof(Md5Plane) * 3 * n, hipMemcpyHostToDevice, c->stream));
+  hr_launch_md5((const Md5Plane *)c->out_dev, 3 * n, dig_dev, c->stream);
+  HIPCHK(c, hipGetLastError());
+  uint8_t *dig_host = (uint8_t *)c->dl_host + desc_bytes;
+  HIPCHK(c, hipMemcpyAsync(dig_host, dig_dev, dig_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < n; i++) {
+    std::memcpy(digests + 48 * i, dig_host + 16 * i, 16);
+    std::memcpy(digests + 48 * i + 16, dig_host + 16 * (n + 2 * i), 32);
+  }
+  return 0;
+}
+
 extern "C" int hevcrecon_debug_keep_stages(hevcrecon_ctx *c, int on) {
   if (!c) return 1;
   c->keep_stages = on != 0;

@@ -15,4 +15,8 @@ void hr_launch(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_
 void hr_launch_output(const void *const planes[3], void *dst, const SeqInfo &s, int width, int height, int file_bd_y, int file_bd_c,
                       bool wide, hipStream_t stream);
 
+// MD5 of n planes (device array `planes`), 16 bytes each into `digests` (device memory).  One lane per plane: the
+// hash is a serial chain, so this only pays with many planes in flight.
+void hr_launch_md5(const Md5Plane *planes, int n, uint8_t *digests, hipStream_t stream);
+
 #endif

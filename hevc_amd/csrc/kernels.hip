@@ -1838,6 +1838,67 @@ __global__ __launch_bounds__(256) void k_output(const pel_t *src, int stride, ui
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_md5: the picture hash of the reference (calcMD5, TLibCommon/TComPicYuvMD5.cpp:188-213; MD5 itself: RFC 1321,
+// the reference's copy is libmd5/libmd5.c): every plane's samples in raster order, one byte per sample up to 8 bits,
+// else two bytes, low byte first -- which is how the planes lie in memory, row padding aside.  One lane per plane.
+// ------------------------------------------------------------------------------------------------
+__constant__ unsigned kMd5K[64] = {
+    0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1,
+    0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453,
+    0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a, 0xfffa3942,
+    0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05,
+    0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d,
+    0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+__constant__ uint8_t kMd5S[16] = {7, 12, 17, 22, 5, 9, 14, 20, 4, 11, 16, 23, 6, 10, 15, 21};
+
+__global__ __launch_bounds__(64) void k_md5(const Md5Plane *planes, int n, uint8_t *digests) {
+  const int idx = blockIdx.x * 64 + threadIdx.x;
+  if (idx >= n) return;
+  const Md5Plane pl = planes[idx];
+  const unsigned long long len = (unsigned long long)pl.row_bytes * pl.rows;
+  const unsigned long long nblocks = (len + 8) / 64 + 1;
+  unsigned a0 = 0x67452301u, b0 = 0xefcdab89u, c0 = 0x98badcfeu, d0 = 0x10325476u;
+  unsigned row = 0, col = 0;  // position of the next message word inside the plane
+  for (unsigned long long blk = 0; blk < nblocks; blk++) {
+    unsigned m[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const unsigned long long pos = blk * 64 + 4 * j;
+      unsigned w = 0;
+      if (pos < len) {
+        w = *(const unsigned *)((const char *)pl.base + (size_t)row * pl.stride_bytes + col);
+        col += 4;
+        if (col == pl.row_bytes) col = 0, row++;
+      } else if (pos == len) {
+        w = 0x80u;
+      } else if (blk == nblocks - 1 && j == 14) {
+        w = (unsigned)(len << 3);
+      } else if (blk == nblocks - 1 && j == 15) {
+        w = (unsigned)((len << 3) >> 32);
+      }
+      m[j] = w;
+    }
+    unsigned a = a0, b = b0, c = c0, d = d0;
+#pragma unroll
+    for (int i = 0; i < 64; i++) {
+      unsigned f;
+      int g;
+      if (i < 16) f = (b & c) | (~b & d), g = i;
+      else if (i < 32) f = (d & b) | (~d & c), g = (5 * i + 1) & 15;
+      else if (i < 48) f = b ^ c ^ d, g = (3 * i + 5) & 15;
+      else f = c ^ (b | ~d), g = (7 * i) & 15;
+      f = f + a + kMd5K[i] + m[g];
+      a = d, d = c, c = b;
+      const int sh = kMd5S[(i >> 4) * 4 + (i & 3)];
+      b = b + ((f << sh) | (f >> (32 - sh)));
+    }
+    a0 += a, b0 += b, c0 += c, d0 += d;
+  }
+  unsigned *out = (unsigned *)(digests + (size_t)idx * 16);
+  out[0] = a0, out[1] = b0, out[2] = c0, out[3] = d0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 #define LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__)
@@ -1910,6 +1971,10 @@ void hr_launch_output(const void *const planes[3], void *dst, const SeqInfo &s, 
     }
     out += (size_t)w * h * ws;
   }
+}
+
+void hr_launch_md5(const Md5Plane *planes, int n, uint8_t *digests, hipStream_t st) {
+  LAUNCH(k_md5, dim3((n + 63) / 64), dim3(64), st, planes, n, digests);
 }
 
 void hr_launch(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t st, int arg, int arg2) {

@@ -128,6 +128,13 @@ class Engine:
                                                              out.ctypes.data, out.nbytes), "hevcrecon_picture_download_file")
         return out
 
+    def md5(self, pic_ids):
+        """Per picture the three plane digests (hex), computed on the device."""
+        n = len(pic_ids)
+        out = np.empty(48 * n, np.uint8)
+        self._check(self.lib.hevcrecon_picture_md5_batch(self.ctx, n, (C.c_int * n)(*pic_ids), out.ctypes.data), "hevcrecon_picture_md5_batch")
+        return [[out[48 * i + 16 * c:48 * i + 16 * c + 16].tobytes().hex() for c in range(3)] for i in range(n)]
+
     def keep_stages(self, on=True):
         self._check(self.lib.hevcrecon_debug_keep_stages(self.ctx, 1 if on else 0), "hevcrecon_debug_keep_stages")
 

@@ -245,6 +245,13 @@ int hevcrecon_picture_download(hevcrecon_ctx *ctx, int pic_id, int16_t *y, int16
 int hevcrecon_picture_download_file(hevcrecon_ctx *ctx, int pic_id, int file_bit_depth_luma, int file_bit_depth_chroma,
                                     int width, int height, void *out, int64_t out_bytes);
 
+/* Replaces calcMD5 (TLibCommon/TComPicYuvMD5.cpp:188-213), the picture hash that TDecGop::calcAndPrintHashStatus
+ * (TLibDecoder/TDecGop.cpp:235) compares with the SEI message, for n resident pictures at once: digests receives
+ * n x 3 x 16 bytes (Y, Cb, Cr of each picture), and only those cross the host link.  MD5 is one serial chain per
+ * plane, so a call takes tens of milliseconds whatever n is (one lane per plane): worth it for batches
+ * (n up to 4096; a picture may be named more than once).  Blocks until done. */
+int hevcrecon_picture_md5_batch(hevcrecon_ctx *ctx, int n, const int *pic_ids, uint8_t *digests);
+
 /* Stage-level parity checks: after hevcrecon_debug_keep_stages(ctx, 1) every reconstruct call also keeps a
  * copy of its first picture before deblocking (stage 0) and after deblocking, before SAO (stage 1). */
 int hevcrecon_debug_keep_stages(hevcrecon_ctx *ctx, int on);

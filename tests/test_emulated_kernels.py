@@ -61,3 +61,22 @@ def test_emulated_output_file_format(emu_lib, stream, depth):
         assert hashlib.md5(data.tobytes()).hexdigest() == want[pic.poc], pic.poc
     syn.close()
     eng.close()
+
+
+@pytest.mark.parametrize("stream", ["randomaccess_he10", "lowdelay_P_main"])
+def test_emulated_device_md5(emu_lib, stream):
+    """hevcrecon_picture_md5_batch: digests of all resident pictures in one call against the digests of the reference
+    decoder's own pictures (8-bit: one byte per sample; 10-bit: two)."""
+    seq = load_golden(stream + "_416x240", 3)
+    eng = engine.Engine(seq.seq_params, lib=emu_lib)
+    syn = eng.new_syntax()
+    for pic in seq.pictures:
+        syn.pack(pic)
+        eng.reconstruct(syn, pic.pic_id)
+    ids = [p.pic_id for p in seq.pictures]
+    assert eng.md5(ids) == [p.stage_md5[2] for p in seq.pictures]
+    assert eng.md5(ids[-1:]) == [seq.pictures[-1].stage_md5[2]]
+    with pytest.raises(engine.EngineError):
+        eng.md5([999])
+    syn.close()
+    eng.close()

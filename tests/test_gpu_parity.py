@@ -102,6 +102,27 @@ def test_output_file_format(stream, depth):
     eng.close()
 
 
+@pytest.mark.parametrize("stream", ["randomaccess_main_416x240", "randomaccess_he10_416x240", "bd12_416x240", "randomaccess_main_1920x1080"])
+def test_device_md5(stream):
+    """hevcrecon_picture_md5_batch: the picture hash computed on the device, all pictures of the stream in one call,
+    against the digests of the reference decoder's own pictures."""
+    seq = load_golden(stream)
+    eng = engine.Engine(seq.seq_params)
+    syn = eng.new_syntax()
+    for pic in seq.pictures:
+        syn.pack(pic)
+        eng.reconstruct(syn, pic.pic_id)
+        pic.drop_ctypes()
+    last = {p.pic_id: p for p in seq.pictures}  # picture ids are buffer slots: a later picture takes over an earlier one's
+    ids = sorted(last)
+    assert eng.md5(ids) == [last[i].stage_md5[2] for i in ids]
+    assert eng.md5(ids[:1]) == [last[ids[0]].stage_md5[2]]
+    with pytest.raises(engine.EngineError):
+        eng.md5([999])
+    syn.close()
+    eng.close()
+
+
 def test_packed_pictures_can_be_uploaded_again():
     """hevcrecon_syntax_upload: a packed picture copied to the device a second time (runs expanded again, while
     other pictures are being reconstructed) gives the same picture; an unfinished one is refused."""
