@@ -111,6 +111,8 @@ def main():
                     help="batch independent pictures of a stream (hierarchical-B siblings) together: 33 instead of 60 batches "
                          "per pass of the RA stream; measured +0.4 %% with one context, -2 %% with two")
     ap.add_argument("--no-handover", action="store_true", help="skip the passes that time the syntax hand-over")
+    ap.add_argument("--check-two-streams-only", action="store_true",
+                    help="parity pass without the device hash of every stream (profiling runs: keeps k_md5 out of the kernel statistics)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -209,8 +211,9 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dist, device="cuda" if backend == "nccl" else "cpu")
 
-    # ---- parity: one more (untimed) pass, every final picture of the first and last stream against the
-    # reference decoder's MD5 right after its batch (the decoder recycles picture ids, so the check cannot wait)
+    # ---- parity: one more (untimed) pass, every final picture against the reference decoder's MD5 right after its
+    # batch (the decoder recycles picture ids, so the check cannot wait): the first and last stream downloaded and
+    # hashed on the host, and every stream hashed on the device (skipped with --check-two-streams-only)
     bd = [sp.bit_depth_luma, sp.bit_depth_chroma, sp.bit_depth_chroma]
     for b in range(nb):
         for c in range(C):
@@ -222,6 +225,10 @@ def main():
                 got = [syntax.plane_md5(planes[c], bd[c]) for c in range(3)]
                 if got != pic.stage_md5[2]:
                     raise SystemExit("bench: stream %d POC %d differs from the reference decoder's MD5" % (s, pic.poc))
+            for c in range(C if not args.check_two_streams_only else 0):
+                for s, got in zip(groups[c], engs[c].md5([ids[t][s] for s in groups[c]])):
+                    if got != pic.stage_md5[2]:
+                        raise SystemExit("bench: stream %d POC %d differs from the reference decoder's MD5 (device hash)" % (s, pic.poc))
 
     # ---- per-kernel time with HIP events on the engine's stream (one extra, untimed step) ----
     # (first context only, scaled by nothing: with several contexts the kernels of different contexts overlap,
@@ -291,7 +298,7 @@ def main():
         "config": {"workload": "%dx%d %d-frame RA stream (encoder_randomaccess_main.cfg), %d independent streams per GPU, "
                                "stream-sharded, no collectives" % (sp.width, sp.height, npic, S),
                    "streams_per_gpu": S, "contexts_per_gpu": C, "frames_per_stream": npic, "batches_per_stream_pass": nb,
-                   "md5_exact": True},
+                   "md5_exact": True, "md5_checked_streams": min(S, 2) if args.check_two_streams_only else S},
         "recon_alg_gbps": round(alg_bytes_stream * S * args.steps / elapsed / 1e9, 2),
         "recon_alg_gbps_gpu_time": round(alg_bytes_stream * S_prof / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None,
         "alg_bytes_per_frame": alg_bytes_stream // npic,
