@@ -108,6 +108,7 @@ EXPORTS = {
     "hevcrecon_create": (C.c_int, [C.POINTER(_P), C.c_int]),
     "hevcrecon_destroy": (None, [_P]),
     "hevcrecon_last_error": (C.c_char_p, [_P]),
+    "hevcrecon_syntax_last_error": (C.c_char_p, [_P]),
     "hevcrecon_sequence_init": (C.c_int, [_P, C.POINTER(SeqParams)]),
     "hevcrecon_syntax_create": (C.c_int, [_P, C.POINTER(_P)]),
     "hevcrecon_syntax_create_detached": (C.c_int, [C.POINTER(SeqParams), C.POINTER(_P)]),

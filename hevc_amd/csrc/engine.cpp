@@ -497,6 +497,8 @@ static int queue_upload(hevcrecon_syntax *s) {
   return 0;
 }
 
+extern "C" const char *hevcrecon_syntax_last_error(const hevcrecon_syntax *s) { return s ? s->err.c_str() : "no syntax object"; }
+
 extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_params *pp) {
   if (!s || !pp) return 1;
   if (!s->pk.finish(pp)) {

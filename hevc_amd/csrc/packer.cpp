@@ -79,6 +79,7 @@ int PackedPicture::coding_order(int ux, int uy) const {
 }
 
 bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
+  if (!error.empty()) return false;  // a refused CTU spoils the picture: begin again
   if (finished || addr < 0 || addr >= seq.ctus_w * seq.ctus_h || ctu_order[addr] >= 0 ||
       (ctu->coding_addr_plus1 ? ctu->coding_addr_plus1 - 1 : addr) != next_ctu) {
     error = "CTUs must be added once each, in coding order";
@@ -98,6 +99,7 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
   ctu_dep_wave = 0;
   const int cx = addr % seq.ctus_w, cy = addr / seq.ctus_w;
   walk_cu(ctu, cx * 64, cy * 64, 0, 0);
+  if (!error.empty()) return false;
   if (!ctu_items.empty()) {
     // blocks of one local level are independent of each other: order the CTU's blocks by level
     int nlev = 0;
@@ -152,6 +154,13 @@ void PackedPicture::walk_cu(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy,
   }
   const int np = (size >> 2) * (size >> 2);
   const bool intra = ctu->pred_mode[z] == 1;
+  // values that index tables on the device are checked on the way (a parser bug must not become a stray access):
+  // the QP range of TComDataCU::setQPSubParts is -QpBDOffset .. 51
+  for (int zz = z; zz < z + np; zz++)
+    if (ctu->qp[zz] < -6 * (seq.bd_y - 8) || ctu->qp[zz] > 51) {
+      error = "QP out of range";
+      return;
+    }
   const bool pcm = intra && ctu->ipcm && ctu->ipcm[z];
   // TComLoopFilter::xEdgeFilterLuma (TLibCommon/TComLoopFilter.cpp:633-641) and xPCMCURestoration
   // (TLibCommon/TComSampleAdaptiveOffset.cpp:1435): lossless units always, IPCM units when the SPS says so
@@ -234,6 +243,11 @@ template <typename T> uint32_t PackedPicture::append_block(const T *src, int nn)
 // Appends one coded transform block: its work item and its coefficients.
 void PackedPicture::emit_tu(const hevcrecon_ctu_syntax *ctu, int comp, int z, int zcu, int x, int y, int log2n, int flags,
                             uint32_t *off_out) {
+  if (log2n < 2 || log2n > 5) {
+    error = "transform block size out of range";
+    if (off_out) *off_out = 0;
+    return;
+  }
   const int n = 1 << log2n, nn = n * n;
   const int32_t *src = ctu->coeff[comp] + (comp ? 4 * z : 16 * z);
   const uint32_t off = append_block(src, nn);
@@ -253,6 +267,10 @@ void PackedPicture::emit_tu(const hevcrecon_ctu_syntax *ctu, int comp, int z, in
 void PackedPicture::inter_tus(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy, int zcu, int comp, int z, int size, int trdepth) {
   if (!((ctu->cbf[comp][z] >> trdepth) & 1)) return;
   if (trdepth < ctu->tr_idx[z]) {
+    if (size <= 4) {
+      error = "transform block size out of range";
+      return;
+    }
     const int np = (size >> 2) * (size >> 2) / 4;
     for (int q = 0; q < 4; q++) inter_tus(ctu, ctux, ctuy, zcu, comp, z + q * np, size >> 1, trdepth + 1);
     return;
@@ -334,6 +352,10 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
   if (comp < 2)  // Cb and Cr share one map; Cr arrives right after Cb with identical geometry
     for (int j = 0; j < nu; j++)
       for (int i = 0; i < nu; i++) lvl[(size_t)(uy0 + j) * seq.uw + ux0 + i] = (uint16_t)level;
+  if (mode < 0 || mode > 34 || log2n < 2 || log2n > 5) {
+    error = mode < 0 || mode > 34 ? "intra prediction mode out of range" : "transform block size out of range";
+    return;
+  }
   IntraItem it;
   std::memset(&it, 0, sizeof(it));
   it.x = (uint16_t)x;
@@ -358,6 +380,10 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
 
 void PackedPicture::intra_tus(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy, int zcu, int z, int size, int trdepth, int chroma) {
   if (trdepth < ctu->tr_idx[z]) {
+    if (size <= 4) {
+      error = "transform block size out of range";
+      return;
+    }
     const int np = (size >> 2) * (size >> 2) / 4;
     for (int q = 0; q < 4; q++) intra_tus(ctu, ctux, ctuy, zcu, z + q * np, size >> 1, trdepth + 1, chroma);
     return;
@@ -380,6 +406,7 @@ void PackedPicture::intra_tus(const hevcrecon_ctu_syntax *ctu, int ctux, int ctu
 }
 
 bool PackedPicture::finish(const hevcrecon_pic_params *p) {
+  if (!error.empty()) return false;
   if (next_ctu != seq.ctus_w * seq.ctus_h) {
     error = "picture closed before all CTUs were added";
     return false;

@@ -155,6 +155,10 @@ typedef struct hevcrecon_pred_weights {
 int hevcrecon_create(hevcrecon_ctx **out, int device);
 void hevcrecon_destroy(hevcrecon_ctx *ctx);
 const char *hevcrecon_last_error(const hevcrecon_ctx *ctx);
+/* The same for a syntax object (the only place to ask when it was created detached): why hevcrecon_syntax_add_ctu or
+ * hevcrecon_syntax_finish refused the picture -- the counterpart of the reference's asserts on parsed values
+ * (e.g. TLibCommon/TComPrediction.cpp:336-338 on block sizes, :488 and :510 on reference indices). */
+const char *hevcrecon_syntax_last_error(const hevcrecon_syntax *syn);
 
 /* Replaces m_cSAO.create / m_cLoopFilter.create in TDecTop::xActivateParameterSets
  * (TLibDecoder/TDecTop.cpp:290-292).  Idempotent when the parameters are unchanged

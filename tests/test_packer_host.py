@@ -127,3 +127,27 @@ def test_ipcm_unit_without_samples_is_refused():
     broken.pcm[0] = None
     assert lib.hevcrecon_syntax_add_ctu(syn.h, a, C.byref(broken)) != 0
     syn.close()
+
+
+@pytest.mark.parametrize("field,value,what", [("qp", 52, "QP"), ("qp", -1, "QP"), ("luma_dir", 35, "intra prediction mode"),
+                                              ("tr_idx", 5, "transform block size")])
+def test_out_of_range_syntax_is_refused(field, value, what):
+    """Values that would index tables on the device are refused by hevcrecon_syntax_add_ctu, and the picture stays
+    refused until hevcrecon_syntax_begin starts it again."""
+    seq = load_golden("intra_main_416x240", 1)
+    pic = seq.pictures[0]
+    lib = abi.load_library()
+    syn = engine.detached_syntax(seq.seq_params)
+    ctus = pic.ctu_structs()
+    broken = abi.CtuSyntax.from_buffer_copy(bytes(ctus[0]))
+    arr = pic.a[field][0].copy()
+    arr[:] = value
+    setattr(broken, field, arr.ctypes.data)
+    assert lib.hevcrecon_syntax_begin(syn.h) == 0
+    assert lib.hevcrecon_syntax_add_ctu(syn.h, 0, C.byref(broken)) != 0
+    assert what in lib.hevcrecon_syntax_last_error(syn.h).decode()
+    assert lib.hevcrecon_syntax_add_ctu(syn.h, 0, C.byref(ctus[0])) != 0
+    assert lib.hevcrecon_syntax_finish(syn.h, C.byref(pic.pic_params)) != 0
+    assert lib.hevcrecon_syntax_begin(syn.h) == 0
+    assert lib.hevcrecon_syntax_add_ctu(syn.h, 0, C.byref(ctus[0])) == 0
+    syn.close()
