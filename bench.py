@@ -102,9 +102,11 @@ def main():
                     help="independent streams per GPU; larger batches amortise the latency-bound intra launches "
                          "(measured: 64 -> 72.9 k, 128 -> 81.6 k, 256 -> 86.4 k frames/s)")
     ap.add_argument("--contexts", type=int, default=2,
-                    help="engine contexts (HIP streams) the streams of this GPU are spread over; with two, one context's "
-                         "latency-bound intra launches run beside the other's throughput-bound kernels "
-                         "(measured at 128 streams: 1 -> 81.9 k, 2 -> 88.7 k frames/s)")
+                    help="engine contexts (HIP streams) the streams of this GPU are spread over; with several, one context's "
+                         "latency-bound intra launches run beside the others' throughput-bound kernels "
+                         "(measured at 128 streams: 1 -> 81.9 k, 2 -> 88.8 k, 3 -> 91.6 k, 4 -> 92.5 k frames/s; beyond two the "
+                         "launches get so small that the latency-bound intra kernel tops the per-kernel times, and the "
+                         "hand-over of fresh pictures suffers from queue sharing)")
     ap.add_argument("--fixture", default="randomaccess_main_1920x1080")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--merge", action="store_true",
