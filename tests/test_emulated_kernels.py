@@ -80,3 +80,26 @@ def test_emulated_device_md5(emu_lib, stream):
         eng.md5([999])
     syn.close()
     eng.close()
+
+
+def _md5_of_uploaded_pictures(lib, width, height, bit_depth):
+    """Random pictures uploaded, hashed on the device and with hashlib: sizes whose planes do not end on a 64-byte
+    block boundary (the golden streams' planes all do)."""
+    from hevc_amd import syntax
+
+    sp = abi.SeqParams(width=width, height=height, bit_depth_luma=bit_depth, bit_depth_chroma=bit_depth, ctu_size=64, max_cu_depth=4)
+    eng = engine.Engine(sp, lib=lib)
+    rng = np.random.default_rng(width * 31 + height + bit_depth)
+    want = []
+    for i in range(3):
+        planes = [rng.integers(0, 1 << bit_depth, size=(h, w)).astype(np.int16) for (w, h) in ((width, height), (width // 2, height // 2), (width // 2, height // 2))]
+        eng.upload(i, i, planes)
+        want.append([syntax.plane_md5(p, bit_depth) for p in planes])
+    assert eng.md5([0, 1, 2]) == want
+    assert eng.md5([2, 2, 0]) == [want[2], want[2], want[0]]
+    eng.close()
+
+
+@pytest.mark.parametrize("width,height,bit_depth", [(8, 8, 8), (72, 40, 8), (424, 248, 8), (72, 40, 10), (8, 8, 12)])
+def test_emulated_device_md5_padding(emu_lib, width, height, bit_depth):
+    _md5_of_uploaded_pictures(emu_lib, width, height, bit_depth)

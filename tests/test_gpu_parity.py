@@ -193,6 +193,25 @@ def test_drop_in_behind_reference_decoder_cli(bits, npics):
     assert out.count("(OK)") == npics and "ERROR" not in out
 
 
+@pytest.mark.parametrize("width,height,bit_depth", [(8, 8, 8), (72, 40, 8), (424, 248, 8), (72, 40, 10), (8, 8, 12)])
+def test_device_md5_padding(width, height, bit_depth):
+    """Plane sizes that do not end on a 64-byte block boundary (the golden streams' planes all do): random pictures
+    uploaded, hashed on the device and with hashlib."""
+    from hevc_amd import abi
+
+    sp = abi.SeqParams(width=width, height=height, bit_depth_luma=bit_depth, bit_depth_chroma=bit_depth, ctu_size=64, max_cu_depth=4)
+    eng = engine.Engine(sp)
+    rng = np.random.default_rng(width * 31 + height + bit_depth)
+    want = []
+    for i in range(3):
+        planes = [rng.integers(0, 1 << bit_depth, size=(h, w)).astype(np.int16) for (w, h) in ((width, height), (width // 2, height // 2), (width // 2, height // 2))]
+        eng.upload(i, i, planes)
+        want.append([syntax.plane_md5(p, bit_depth) for p in planes])
+    assert eng.md5([0, 1, 2]) == want
+    assert eng.md5([2, 2, 0]) == [want[2], want[2], want[0]]
+    eng.close()
+
+
 BENCH_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"}
 
@@ -228,3 +247,4 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
                      "29533", "bench.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--streams", "2", "--no-cpu-baseline"],
                     env={"HEVCRECON_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+
