@@ -107,6 +107,7 @@ _I16P = C.c_void_p
 EXPORTS = {
     "hevcrecon_create": (C.c_int, [C.POINTER(_P), C.c_int]),
     "hevcrecon_destroy": (None, [_P]),
+    "hevcrecon_set_upload_ring": (C.c_int, [_P, C.c_int64]),
     "hevcrecon_last_error": (C.c_char_p, [_P]),
     "hevcrecon_syntax_last_error": (C.c_char_p, [_P]),
     "hevcrecon_sequence_init": (C.c_int, [_P, C.POINTER(SeqParams)]),

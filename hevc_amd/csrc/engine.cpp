@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <deque>
 #include <vector>
 #include "../../include/hevcrecon.h"
 #include "common.h"
@@ -106,6 +107,18 @@ struct hevcrecon_ctx {
   hipEvent_t copy_ev[kRing * kCopyStreams];  // recorded on the copy streams when the main stream has to wait for uploads
   int copy_ev_pos = 0;
   int ring_pos = 0;
+  // Upload ring: packed pictures are staged in one pinned buffer in the order they are finished, mirrored by one
+  // device buffer at the same offsets, so that the pictures of a batch, finished one after the other, cross the host
+  // link in a few large copies instead of one copy command each.  Space is handed out in ring order and taken back
+  // in the same order; a picture that does not fit (the ring is full of pictures still in use) gets buffers of its own.
+  struct RingEntry {
+    size_t off, bytes;
+    bool live;
+  };
+  char *up_host = nullptr, *up_dev = nullptr;
+  size_t up_bytes = (size_t)64 << 20, up_head = 0;
+  bool up_failed = false;
+  std::deque<RingEntry> up_entries;  // in allocation order (references stay valid across push_back / pop_front)
   int32_t *error_flag_dev = nullptr;
   void *dl_host = nullptr;  // pinned staging for downloads / uploads
   void *out_dev = nullptr;  // a picture in file format (hevcrecon_picture_download_file)
@@ -125,7 +138,9 @@ struct hevcrecon_syntax {
   SeqInfo si;
   char *dev = nullptr;
   size_t dev_cap = 0;
-  char *host = nullptr;  // pinned staging
+  char *host = nullptr;  // pinned staging of its own (when the context's upload ring had no room)
+  char *up_host = nullptr, *up_dev = nullptr;  // where the packed picture is staged and where its device copy lies
+  hevcrecon_ctx::RingEntry *up_entry = nullptr;  // its space in the upload ring, if it got any
   bool dirty = false;    // the staging buffer holds a picture the device copy does not have yet
   size_t host_cap = 0;
   size_t upload_bytes = 0, off_runs = 0, off_runoff = 0;
@@ -142,6 +157,46 @@ namespace {
 int fail(hevcrecon_ctx *c, const std::string &m) {
   if (c) c->err = m;
   return 1;
+}
+
+// Space in the upload ring (bytes is a multiple of 256), or NULL when there is none.
+hevcrecon_ctx::RingEntry *ring_alloc(hevcrecon_ctx *c, size_t bytes) {
+  if (c->up_failed || c->up_bytes == 0 || bytes == 0 || bytes > c->up_bytes) return nullptr;
+  if (!c->up_host) {
+    if (hipHostMalloc((void **)&c->up_host, c->up_bytes) != hipSuccess) c->up_host = nullptr;
+    if (c->up_host && hipMalloc((void **)&c->up_dev, c->up_bytes) != hipSuccess) {
+      hipHostFree(c->up_host);
+      c->up_host = nullptr;
+    }
+    if (!c->up_host) {
+      (void)hipGetLastError();
+      c->up_failed = true;
+      return nullptr;
+    }
+  }
+  while (!c->up_entries.empty() && !c->up_entries.front().live) c->up_entries.pop_front();
+  size_t off;
+  if (c->up_entries.empty()) {
+    off = 0;
+  } else {
+    const size_t tail = c->up_entries.front().off, head = c->up_head;
+    if (head > tail) {  // free: [head, end) and [0, tail)
+      if (bytes <= c->up_bytes - head) off = head;
+      else if (bytes <= tail) off = 0;
+      else return nullptr;
+    } else {  // wrapped: free is [head, tail), nothing when they meet
+      if (bytes <= tail - head) off = head;
+      else return nullptr;
+    }
+  }
+  c->up_entries.push_back(hevcrecon_ctx::RingEntry{off, bytes, true});
+  c->up_head = off + bytes;
+  return &c->up_entries.back();
+}
+
+void ring_release(hevcrecon_syntax *s) {
+  if (s->up_entry) s->up_entry->live = false;
+  s->up_entry = nullptr;
 }
 #define HIPCHK(c, call)                                                                       \
   do {                                                                                        \
@@ -348,12 +403,23 @@ extern "C" void hevcrecon_destroy(hevcrecon_ctx *c) {
   if (c->error_flag_dev) hipFree(c->error_flag_dev);
   if (c->dl_host) hipHostFree(c->dl_host);
   if (c->out_dev) hipFree(c->out_dev);
+  if (c->up_host) hipHostFree(c->up_host);
+  if (c->up_dev) hipFree(c->up_dev);
   hipStreamDestroy(c->stream);
   if (c->have_copy_streams) {
     for (int i = 0; i < kCopyStreams; i++) hipStreamSynchronize(c->copy_stream[i]);
     release_copy_streams(c->device);
   }
   delete c;
+}
+
+extern "C" int hevcrecon_set_upload_ring(hevcrecon_ctx *c, int64_t bytes) {
+  if (!c) return 1;
+  if (c->up_host) return fail(c, "the upload ring is already in use");
+  if (bytes < 0 || bytes > ((int64_t)64 << 30)) return fail(c, "upload ring size out of range");
+  c->up_bytes = align_up((size_t)bytes, 256);
+  c->up_failed = false;
+  return 0;
 }
 
 extern "C" const char *hevcrecon_last_error(const hevcrecon_ctx *c) { return c ? c->err.c_str() : "no context (is a GPU present?)"; }
@@ -423,6 +489,7 @@ extern "C" void hevcrecon_syntax_destroy(hevcrecon_syntax *s) {
     for (int k = 0; k < kCopyStreams; k++) hipStreamSynchronize(s->ctx->copy_stream[k]);
     hipStreamSynchronize(s->ctx->stream);
   }
+  ring_release(s);
   if (s->dev) hipFree(s->dev);
   if (s->host) hipHostFree(s->host);
   delete s;
@@ -443,7 +510,9 @@ extern "C" int hevcrecon_syntax_begin(hevcrecon_syntax *s) {
       if (s->last_batch >= 0) hipEventSynchronize(s->ctx->batch_ev[s->last_batch % kRing]);
     }
   }
+  ring_release(s);  // nothing reads the previous picture any more (waited for above)
   s->uploaded = false;
+  s->dirty = false;
   s->last_batch = -1;
   s->pk.begin(s->si);
   return 0;
@@ -542,27 +611,36 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
     HIPCHK(c, hipMalloc((void **)&s->dev, cap));
     s->dev_cap = cap;
   }
-  if (s->host_cap < upload_bytes) {
-    if (s->host) hipHostFree(s->host);
-    s->host = nullptr;
-    s->host_cap = 0;
-    const size_t cap = upload_bytes + upload_bytes / 4;
-    HIPCHK(c, hipHostMalloc((void **)&s->host, cap));
-    s->host_cap = cap;
+  ring_release(s);
+  s->up_entry = ring_alloc(c, upload_bytes);
+  if (s->up_entry) {
+    s->up_host = c->up_host + s->up_entry->off;
+    s->up_dev = c->up_dev + s->up_entry->off;
+  } else {
+    if (s->host_cap < upload_bytes) {
+      if (s->host) hipHostFree(s->host);
+      s->host = nullptr;
+      s->host_cap = 0;
+      const size_t cap = upload_bytes + upload_bytes / 4;
+      HIPCHK(c, hipHostMalloc((void **)&s->host, cap));
+      s->host_cap = cap;
+    }
+    s->up_host = s->host;
+    s->up_dev = s->dev;
   }
-  std::memcpy(s->host + s->off_runs, k.runs.data(), k.runs.size() * sizeof(Part4));
-  std::memcpy(s->host + s->off_runoff, k.ctu_run_off.data(), k.ctu_run_off.size() * sizeof(uint32_t));
-  for (int i = 0; i < 4; i++) std::memcpy(s->host + s->off_tu[i], k.tu[i].data(), k.tu[i].size() * sizeof(TuItem));
-  std::memcpy(s->host + s->off_coeff, k.coeff.data(), k.coeff.size() * sizeof(uint32_t));
-  std::memcpy(s->host + s->off_intra, k.intra.data(), k.intra.size() * sizeof(IntraItem));
-  std::memcpy(s->host + s->off_ictu, k.ictu.data(), k.ictu.size() * sizeof(IntraCtu));
-  std::memcpy(s->host + s->off_lvlc, k.lvl_counts.data(), k.lvl_counts.size() * sizeof(uint16_t));
-  std::memcpy(s->host + s->off_wave, k.wave_off.data(), k.wave_off.size() * sizeof(int32_t));
-  std::memcpy(s->host + s->off_sao, k.sao.data(), k.sao.size() * sizeof(SaoCtu));
-  for (int i = 0; i < 3; i++) std::memcpy(s->host + s->off_mct[i], k.mc_tile[i].data(), k.mc_tile[i].size() * sizeof(McTile));
-  std::memcpy(s->host + s->off_mcb, k.mc_blk.data(), k.mc_blk.size() * sizeof(McBlk));
-  std::memcpy(s->host + s->off_scal, &k.scaling, sizeof(ScalingTables));
-  std::memcpy(s->host + s->off_wp, &k.wp, sizeof(WpTables));
+  std::memcpy(s->up_host + s->off_runs, k.runs.data(), k.runs.size() * sizeof(Part4));
+  std::memcpy(s->up_host + s->off_runoff, k.ctu_run_off.data(), k.ctu_run_off.size() * sizeof(uint32_t));
+  for (int i = 0; i < 4; i++) std::memcpy(s->up_host + s->off_tu[i], k.tu[i].data(), k.tu[i].size() * sizeof(TuItem));
+  std::memcpy(s->up_host + s->off_coeff, k.coeff.data(), k.coeff.size() * sizeof(uint32_t));
+  std::memcpy(s->up_host + s->off_intra, k.intra.data(), k.intra.size() * sizeof(IntraItem));
+  std::memcpy(s->up_host + s->off_ictu, k.ictu.data(), k.ictu.size() * sizeof(IntraCtu));
+  std::memcpy(s->up_host + s->off_lvlc, k.lvl_counts.data(), k.lvl_counts.size() * sizeof(uint16_t));
+  std::memcpy(s->up_host + s->off_wave, k.wave_off.data(), k.wave_off.size() * sizeof(int32_t));
+  std::memcpy(s->up_host + s->off_sao, k.sao.data(), k.sao.size() * sizeof(SaoCtu));
+  for (int i = 0; i < 3; i++) std::memcpy(s->up_host + s->off_mct[i], k.mc_tile[i].data(), k.mc_tile[i].size() * sizeof(McTile));
+  std::memcpy(s->up_host + s->off_mcb, k.mc_blk.data(), k.mc_blk.size() * sizeof(McBlk));
+  std::memcpy(s->up_host + s->off_scal, &k.scaling, sizeof(ScalingTables));
+  std::memcpy(s->up_host + s->off_wp, &k.wp, sizeof(WpTables));
   return queue_upload(s);
 }
 
@@ -711,35 +789,35 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
         j.ref_poc[l][r] = k.pp.ref_poc[l][r];
       }
     j.rec4 = (const Part4 *)(y->dev + y->off_rec4);
-    j.runs = (const Part4 *)(y->dev + y->off_runs);
-    j.ctu_run_off = (const uint32_t *)(y->dev + y->off_runoff);
+    j.runs = (const Part4 *)(y->up_dev + y->off_runs);
+    j.ctu_run_off = (const uint32_t *)(y->up_dev + y->off_runoff);
     j.need_expand = y->expanded ? 0 : 1;
     any_expand = any_expand || !y->expanded;
     y->expanded = true;
     for (int t = 0; t < 3; t++) {
-      j.mc_tile[t] = (const McTile *)(y->dev + y->off_mct[t]);
+      j.mc_tile[t] = (const McTile *)(y->up_dev + y->off_mct[t]);
       j.n_mc_tile[t] = (int)k.mc_tile[t].size();
       max_mct[t] = std::max(max_mct[t], j.n_mc_tile[t]);
     }
-    j.mc_blk = (const McBlk *)(y->dev + y->off_mcb);
+    j.mc_blk = (const McBlk *)(y->up_dev + y->off_mcb);
     j.n_mc_blk = (int)k.mc_blk.size();
     max_mcb = std::max(max_mcb, j.n_mc_blk);
     for (int t = 0; t < 4; t++) {
-      j.tu[t] = (const TuItem *)(y->dev + y->off_tu[t]);
+      j.tu[t] = (const TuItem *)(y->up_dev + y->off_tu[t]);
       j.n_tu[t] = (int)k.tu[t].size();
       if (j.n_tu[t] > max_tu[t]) max_tu[t] = j.n_tu[t];
     }
-    j.coeff = (const uint32_t *)(y->dev + y->off_coeff);
+    j.coeff = (const uint32_t *)(y->up_dev + y->off_coeff);
     for (int p = 0; p < 3; p++) j.resi[p] = (int16_t *)((char *)c->work_resi[i] + c->resi_off[p]);
-    j.intra = (const IntraItem *)(y->dev + y->off_intra);
-    j.ictu = (const IntraCtu *)(y->dev + y->off_ictu);
-    j.lvl_counts = (const uint16_t *)(y->dev + y->off_lvlc);
-    j.wave_off = (const int32_t *)(y->dev + y->off_wave);
+    j.intra = (const IntraItem *)(y->up_dev + y->off_intra);
+    j.ictu = (const IntraCtu *)(y->up_dev + y->off_ictu);
+    j.lvl_counts = (const uint16_t *)(y->up_dev + y->off_lvlc);
+    j.wave_off = (const int32_t *)(y->up_dev + y->off_wave);
     j.n_waves = k.wave_off.empty() ? 0 : (int)k.wave_off.size() - 1;
     if (j.n_waves > max_levels) max_levels = j.n_waves;
-    j.sao = (const SaoCtu *)(y->dev + y->off_sao);
-    j.scaling = k.use_scaling ? (const ScalingTables *)(y->dev + y->off_scal) : nullptr;
-    j.wp = k.use_wp ? (const WpTables *)(y->dev + y->off_wp) : nullptr;
+    j.sao = (const SaoCtu *)(y->up_dev + y->off_sao);
+    j.scaling = k.use_scaling ? (const ScalingTables *)(y->up_dev + y->off_scal) : nullptr;
+    j.wp = k.use_wp ? (const WpTables *)(y->up_dev + y->off_wp) : nullptr;
     any_wp = any_wp || k.use_wp;
     j.slice_type = k.pp.slice_type;
     j.deblock_disable = k.pp.deblocking_disable;
@@ -770,13 +848,29 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
         for (int k = 0; k < kCopyStreams; k++) HIPCHK(c, hipStreamWaitEvent(c->copy_stream[k], c->batch_ev[newest_reader % kRing], 0));
         c->batch_waited = newest_reader;
       }
-      for (int i = 0; i < n; i++) {
-        hevcrecon_syntax *y = syn[i];
-        if (!y->dirty) continue;
-        HIPCHK(c, hipMemcpyAsync(y->dev, y->host, y->upload_bytes, hipMemcpyHostToDevice, c->copy_stream[c->copy_rr]));
-        c->copy_rr = (c->copy_rr + 1) % kCopyStreams;
-        y->dirty = false;
-        y->upload_seq = c->upload_no;
+      // pictures that lie back to back in the upload ring travel in one copy (cut into pieces of a few megabytes so
+      // that the copy streams share the work)
+      const size_t kPiece = (size_t)8 << 20;
+      char *run_h = nullptr, *run_d = nullptr;
+      size_t run_n = 0;
+      for (int i = 0; i <= n; i++) {
+        hevcrecon_syntax *y = i < n ? syn[i] : nullptr;
+        if (y && !y->dirty) continue;
+        if (y && run_n && run_n + y->upload_bytes <= kPiece && y->up_host == run_h + run_n && y->up_dev == run_d + run_n) {
+          run_n += y->upload_bytes;
+        } else {
+          if (run_n) {
+            HIPCHK(c, hipMemcpyAsync(run_d, run_h, run_n, hipMemcpyHostToDevice, c->copy_stream[c->copy_rr]));
+            c->copy_rr = (c->copy_rr + 1) % kCopyStreams;
+          }
+          run_h = y ? y->up_host : nullptr;
+          run_d = y ? y->up_dev : nullptr;
+          run_n = y ? y->upload_bytes : 0;
+        }
+        if (y) {
+          y->dirty = false;
+          y->upload_seq = c->upload_no;
+        }
       }
       c->upload_no++;
     }

@@ -128,6 +128,9 @@ class Engine:
                                                              out.ctypes.data, out.nbytes), "hevcrecon_picture_download_file")
         return out
 
+    def set_upload_ring(self, nbytes):
+        self._check(self.lib.hevcrecon_set_upload_ring(self.ctx, int(nbytes)), "hevcrecon_set_upload_ring")
+
     def md5(self, pic_ids):
         """Per picture the three plane digests (hex), computed on the device."""
         n = len(pic_ids)

@@ -154,6 +154,13 @@ typedef struct hevcrecon_pred_weights {
 /* Creates an engine on HIP device `device`.  Fails (non-zero, *out = NULL) when no GPU is present. */
 int hevcrecon_create(hevcrecon_ctx **out, int device);
 void hevcrecon_destroy(hevcrecon_ctx *ctx);
+/* No counterpart in the reference.  Packed pictures wait for their trip to the device in one pinned ring per context
+ * (and its mirror in device memory), so that pictures finished one after the other and reconstructed in one batch
+ * cross the host link in a few large copies.  Default 64 MB, allocated when the first picture is finished; call this
+ * before that to choose another size (0: no ring, every syntax object stages in buffers of its own, which is also
+ * what happens to a picture the ring has no room for).  A host that keeps many packed pictures alive sizes the
+ * ring for all of them. */
+int hevcrecon_set_upload_ring(hevcrecon_ctx *ctx, int64_t bytes);
 const char *hevcrecon_last_error(const hevcrecon_ctx *ctx);
 /* The same for a syntax object (the only place to ask when it was created detached): why hevcrecon_syntax_add_ctu or
  * hevcrecon_syntax_finish refused the picture -- the counterpart of the reference's asserts on parsed values

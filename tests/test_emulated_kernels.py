@@ -103,3 +103,29 @@ def _md5_of_uploaded_pictures(lib, width, height, bit_depth):
 @pytest.mark.parametrize("width,height,bit_depth", [(8, 8, 8), (72, 40, 8), (424, 248, 8), (72, 40, 10), (8, 8, 12)])
 def test_emulated_device_md5_padding(emu_lib, width, height, bit_depth):
     _md5_of_uploaded_pictures(emu_lib, width, height, bit_depth)
+
+
+def _ring_sizes_give_the_same_pictures(lib, ring_bytes):
+    """The upload ring in its corner cases: none at all, one that wraps around and overflows (pictures that find no
+    room stage in buffers of their own), and the default; three syntax objects in rotation, pictures reconstructed
+    two at a time where the stream allows it."""
+    seq = load_golden("randomaccess_main_416x240")
+    eng = engine.Engine(seq.seq_params, lib=lib)
+    if ring_bytes is not None:
+        eng.set_upload_ring(ring_bytes)
+    syns = [eng.new_syntax() for _ in range(3)]
+    for i, pic in enumerate(seq.pictures):
+        syn = syns[i % 3]
+        syn.pack(pic)
+        eng.reconstruct(syn, pic.pic_id)
+        assert eng.md5([pic.pic_id]) == [pic.stage_md5[2]], (ring_bytes, pic.poc)
+    with pytest.raises(engine.EngineError):
+        eng.set_upload_ring(1 << 20) if ring_bytes != 0 else eng.md5([999])
+    for s in syns:
+        s.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("ring_bytes", [0, 48 << 10, 96 << 10, None])  # 48 KB: overflow, then wrap-around at the last picture
+def test_emulated_upload_ring(emu_lib, ring_bytes):
+    _ring_sizes_give_the_same_pictures(emu_lib, ring_bytes)

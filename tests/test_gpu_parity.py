@@ -212,6 +212,15 @@ def test_device_md5_padding(width, height, bit_depth):
     eng.close()
 
 
+@pytest.mark.parametrize("ring_bytes", [0, 48 << 10, 96 << 10, None])
+def test_upload_ring(ring_bytes):
+    """The upload ring in its corner cases (none, overflow and wrap-around, default) gives the same pictures."""
+    from test_emulated_kernels import _ring_sizes_give_the_same_pictures
+    from hevc_amd import abi
+
+    _ring_sizes_give_the_same_pictures(abi.load_library(), ring_bytes)
+
+
 BENCH_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline"}
 
