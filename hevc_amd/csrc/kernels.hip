@@ -336,8 +336,8 @@ __device__ __forceinline__ PredRound pred_round(const WpTables *wp, int r0, int 
   } else {
     const int l = r0 >= 0 ? 0 : 1, r = l ? r1 : r0;
     const int w = wp->w[l][r][comp];
-    R.w[l] = w;
-    R.w[l ^ 1] = 0;
+    R.w[0] = l ? 0 : w;  // (not R.w[l]: an array indexed by a run-time value lives in scratch memory)
+    R.w[1] = l ? w : 0;
     R.sh = wp->log2d[l][r][comp] + head;
     R.add = w * 8192 + (R.sh ? 1 << (R.sh - 1) : 0);
     R.post = wp->o[l][r][comp] * (1 << (bd - 8));
