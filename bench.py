@@ -313,7 +313,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                      "alg_bytes_per_launch": int(kb[dom] * S_prof / max(dom_launches, 1)),
-                     "launches_per_step": int(dom_launches), "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 3)},
+                     "launches_per_step": int(dom_launches), "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 3),
+                     "pictures_per_launch": S_prof, "timed_in": "a pass of one context alone (HIP events on its stream)"},
         "kernels": kernels,
     }
     if handover is not None:
