@@ -63,7 +63,7 @@ def test_emulated_output_file_format(emu_lib, stream, depth):
     eng.close()
 
 
-@pytest.mark.parametrize("stream", ["randomaccess_he10", "lowdelay_P_main"])
+@pytest.mark.parametrize("stream", ["randomaccess_he10"])  # 8-bit planes: the padding test below and the GPU suite
 def test_emulated_device_md5(emu_lib, stream):
     """hevcrecon_picture_md5_batch: digests of all resident pictures in one call against the digests of the reference
     decoder's own pictures (8-bit: one byte per sample; 10-bit: two)."""
@@ -126,6 +126,6 @@ def _ring_sizes_give_the_same_pictures(lib, ring_bytes):
     eng.close()
 
 
-@pytest.mark.parametrize("ring_bytes", [0, 48 << 10, 96 << 10, None])  # 48 KB: overflow, then wrap-around at the last picture
+@pytest.mark.parametrize("ring_bytes", [48 << 10])  # 48 KB: overflow, then wrap-around at the last picture (more sizes in the GPU suite)
 def test_emulated_upload_ring(emu_lib, ring_bytes):
     _ring_sizes_give_the_same_pictures(emu_lib, ring_bytes)
