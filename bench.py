@@ -93,6 +93,25 @@ def cpu_baseline(seconds_target=12.0):
             "sample": "first %d pictures of the 1080p RA stream through oracle/recon_ref.c (reconstruction only), %.1f s" % (len(seq.pictures), dt)}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh copies of this script, one rank per GPU, before this
+    process has touched a GPU (it never does), pass rank 0's line through and return the worst exit status."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,8 +135,14 @@ def main():
     ap.add_argument("--upload-ring", action="store_true", help="stage all packed pictures in the context's upload ring (coalesced hand-over copies)")
     ap.add_argument("--check-two-streams-only", action="store_true",
                     help="parity pass without the device hash of every stream (profiling runs: keeps k_md5 out of the kernel statistics)")
+    ap.add_argument("--rehearse", action="store_true", help="no GPU work: only the multi-rank plumbing (used by the CPU tests)")
+    ap.add_argument("--total-streams", type=int, default=0,
+                    help="streams of the whole job, dealt to the GPUs round-robin (stream i -> rank i mod N); overrides --streams: "
+                         "64 on 8 GPUs is 8 independent streams per GPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,12 +153,34 @@ def main():
         import torch.distributed as dist
 
         ndev = torch.cuda.device_count()
-        if backend == "nccl" and local_rank >= ndev:
+        if args.rehearse:
+            backend = "gloo"
+        elif backend == "nccl" and local_rank >= ndev:
             raise SystemExit("bench: rank %d has no GPU of its own (%d visible)" % (local_rank, ndev))
         local_rank = local_rank % max(ndev, 1)
-        torch.cuda.set_device(local_rank)
+        if ndev:
+            torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
 
+    if args.rehearse:
+        # the N > 1 plumbing alone (spawn, rendezvous, stream sharding, barrier, reductions), for machines without a GPU
+        mine = sharding.streams_for_rank(args.total_streams or args.streams * world, rank, world)
+        if dist is not None:
+            dist.barrier()
+        t = sharding.max_over_ranks(1.0 + rank, dist)
+        total = sharding.sum_over_ranks(len(mine), dist)
+        if rank == 0:
+            print(json.dumps({"rehearsal": True, "value": None, "n_gpus": world, "streams_total": int(total),
+                              "streams_rank0": mine, "max_over_ranks": t}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    if args.gpus != world:
+        raise SystemExit("bench: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    if args.total_streams:
+        args.streams = len(sharding.streams_for_rank(args.total_streams, rank, world))
+        if args.streams == 0:
+            raise SystemExit("bench: fewer streams than GPUs")
     seq = syntax.read_dump(os.path.join(ROOT, "tests", "golden", args.fixture + ".syn.xz"))
     sp = seq.seq_params
     npic, S = len(seq.pictures), args.streams
@@ -288,7 +335,7 @@ def main():
         handover = {"bytes_per_frame": up_bytes // npic, "with_reconstruction_frames_per_s": round(npic * S / t_both, 1),
                     "link_gbps": round(up_bytes * S / t_both / 1e9, 2)}
 
-    frames_total = npic * S * args.steps * world
+    frames_total = sharding.sum_over_ranks(npic * S * args.steps, dist, device="cuda" if backend == "nccl" else "cpu")
     value = frames_total / elapsed
     result = {
         "metric": "1080p_ra_reconstructed_frames_per_s",

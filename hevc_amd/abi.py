@@ -130,6 +130,7 @@ EXPORTS = {
     "hevcrecon_debug_keep_stages": (C.c_int, [_P, C.c_int]),
     "hevcrecon_debug_download_stage": (C.c_int, [_P, C.c_int, _I16P, _I16P, _I16P, C.c_int, C.c_int]),
     "hevcrecon_picture_upload": (C.c_int, [_P, C.c_int, C.c_int, _I16P, _I16P, _I16P, C.c_int, C.c_int]),
+    "hevcrecon_picture_copy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
     "hevcrecon_picture_release": (C.c_int, [_P, C.c_int]),
     "hevcrecon_synchronize": (C.c_int, [_P]),
     "hevcrecon_profile_enable": (C.c_int, [_P, C.c_int]),

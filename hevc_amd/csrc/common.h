@@ -95,12 +95,20 @@ struct IntraItem {
   uint32_t resi_off;
 };
 
+/* IntraCtu.deps: neighbouring CTUs whose intra blocks this CTU's blocks read (it has to wait for them) */
+#define IC_DEP_LEFT 1
+#define IC_DEP_ABOVE_LEFT 2
+#define IC_DEP_ABOVE 4
+#define IC_DEP_ABOVE_RIGHT 8
+
 struct IntraCtu {
   uint32_t item_start; /* first IntraItem of this CTU */
   uint32_t lvl_start;  /* first entry of this CTU in lvl_counts[] */
   uint16_t n_items;
   uint16_t n_lvl;      /* local dependency levels */
-  uint16_t cx, cy;     /* CTU position in CTUs */
+  uint8_t cx, cy;      /* CTU position in CTUs (pictures are at most 8192 samples = 128 CTUs wide and high) */
+  uint8_t deps;        /* IC_DEP_* */
+  uint8_t pad;
 };
 
 // De-quantisation matrices of a picture that uses scaling lists (same content as hevcrecon_scaling_lists).
@@ -162,6 +170,8 @@ struct PicJob {
   const uint16_t *lvl_counts; /* per CTU: number of intra blocks at each local level */
   const int32_t *wave_off;    /* n_waves + 1 entries into ictu[] */
   int32_t n_waves;
+  uint32_t *ctu_done;         /* one word per CTU (raster), zero when the batch starts: set by the intra kernel once the
+                                 CTU's intra blocks are in the picture */
   const SaoCtu *sao;
   const ScalingTables *scaling; /* NULL: flat de-quantisation */
   const WpTables *wp;           /* NULL: default (un)weighted prediction */
@@ -174,6 +184,11 @@ struct PicJob {
   int32_t has_pcm;    /* some coding unit is IPCM: its samples are in the picture before the intra kernel runs */
   int32_t *error_flag;
 };
+
+// Bits the kernels raise in PicJob::error_flag[0]
+#define HR_ERR_EXPAND 1          /* k_expand: a 4x4 unit inside the picture is covered by no run */
+#define HR_ERR_INTRA_CAPACITY 2  /* k_intra: a CTU with more blocks or levels than HR_INTRA_MAX_ITEMS / _LEVELS */
+#define HR_ERR_INTRA_TIMEOUT 4   /* k_intra: the wait for a neighbouring CTU ran out */
 
 #define HR_MD5_MAX_PICTURES 4096  // pictures per hevcrecon_picture_md5_batch call
 

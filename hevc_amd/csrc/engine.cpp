@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #endif
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -93,18 +94,24 @@ struct hevcrecon_ctx {
   std::vector<void *> work_resi;  // per batch slot: int16 residual planes, same geometry as a picture
   DevPicture stage[2];
   bool keep_stages = false;
+  // Scheduling words of the intra kernel (a ticket counter, then one "done" word per CTU of every picture of the
+  // batch), zeroed before each launch, and the pinned ring + device copy of the batch's CTU list.  Both grow on demand.
+  uint32_t *sync_dev = nullptr;
+  size_t sync_words = 0;
+  uint32_t *list_host = nullptr, *list_dev = nullptr;  // kRing slots of list_cap entries
+  size_t list_cap = 0;
   PicJob *jobs_host = nullptr;  // pinned ring: kRing slots of HR_MAX_BATCH jobs
   PicJob *jobs_dev = nullptr;
-  hipEvent_t ring_ev[kRing];
+  hipEvent_t ring_ev[kRing] = {};
   bool ring_used[kRing];
   // "batch done" events: slot b % kRing is recorded behind batch b's last kernel.  A later batch's event in the
   // same slot also implies batch b is done (one stream), so waiting on the slot is always sufficient.
-  hipEvent_t batch_ev[kRing];
+  hipEvent_t batch_ev[kRing] = {};
   int64_t batch_no = 0;
   // Cross-stream waits are expensive, and both streams run in order: the main stream waits for an upload only
   // when it is newer than the newest one it has already waited for, and the copy streams likewise for batches.
   int64_t upload_no = 0, upload_waited = -1, upload_synced = -1, batch_waited = -1;
-  hipEvent_t copy_ev[kRing * kCopyStreams];  // recorded on the copy streams when the main stream has to wait for uploads
+  hipEvent_t copy_ev[kRing * kCopyStreams] = {};  // recorded on the copy streams when the main stream has to wait for uploads
   int copy_ev_pos = 0;
   int ring_pos = 0;
   // Upload ring: packed pictures are staged in one pinned buffer in the order they are finished, mirrored by one
@@ -119,7 +126,9 @@ struct hevcrecon_ctx {
   size_t up_bytes = (size_t)64 << 20, up_head = 0;
   bool up_failed = false;
   std::deque<RingEntry> up_entries;  // in allocation order (references stay valid across push_back / pop_front)
-  int32_t *error_flag_dev = nullptr;
+  int32_t *error_flag_dev = nullptr;  // 16 words the kernels raise when they meet something the packer should have refused
+  int32_t *error_host = nullptr;      // pinned: where hevcrecon_synchronize reads them
+  int longest_intra_wait = 0;         // polls of the longest wait of an intra CTU for a neighbour seen so far (word 8)
   void *dl_host = nullptr;  // pinned staging for downloads / uploads
   void *out_dev = nullptr;  // a picture in file format (hevcrecon_picture_download_file)
   size_t out_cap = 0;
@@ -264,8 +273,11 @@ hipEvent_t get_event(hevcrecon_ctx *c) {
     c->event_pool.pop_back();
     return e;
   }
-  hipEvent_t e;
-  hipEventCreate(&e);
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;  // the interval is dropped (Timed checks), the launches go ahead untimed
+  }
   return e;
 }
 
@@ -273,18 +285,22 @@ struct Timed {
   hevcrecon_ctx *c;
   int kind;
   hipEvent_t a = nullptr;
-  Timed(hevcrecon_ctx *c_, int kind_, int nlaunch) : c(c_), kind(kind_) {
+  Timed(hevcrecon_ctx *c_, int kind_, int nlaunch, bool enabled = true) : c(c_), kind(kind_) {
     c->launches[kind] += nlaunch;
-    if (c->profiling) {
+    if (c->profiling && enabled) {
       a = get_event(c);
-      hipEventRecord(a, c->stream);
+      if (a) hipEventRecord(a, c->stream);
     }
   }
   ~Timed() {
     if (a) {
       hipEvent_t b = get_event(c);
-      hipEventRecord(b, c->stream);
-      c->intervals.push_back(Interval{kind, a, b});
+      if (b) {
+        hipEventRecord(b, c->stream);
+        c->intervals.push_back(Interval{kind, a, b});
+      } else {
+        c->event_pool.push_back(a);
+      }
     }
   }
 };
@@ -314,6 +330,29 @@ int ensure_staging(hevcrecon_ctx *c, size_t n) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// The kernels raise bits in the context's error words instead of indexing out of range when they meet work lists
+// the packer should never produce (and when a dependency wait runs out).  Read after the stream has drained.
+int check_device_errors(hevcrecon_ctx *c) {
+  HIPCHK(c, hipMemcpyAsync(c->error_host, c->error_flag_dev, 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int bits = c->error_host[0];
+  c->longest_intra_wait = std::max(c->longest_intra_wait, c->error_host[8]);
+  if (!bits) return 0;
+  HIPCHK(c, hipMemsetAsync(c->error_flag_dev, 0, 64, c->stream));
+  std::string m = "the device rejected a work list:";
+  if (bits & HR_ERR_EXPAND) m += " motion record runs do not cover a CTU;";
+  if (bits & HR_ERR_INTRA_CAPACITY) m += " a CTU holds more intra blocks or levels than the kernel's tables;";
+  if (bits & HR_ERR_INTRA_TIMEOUT) {
+    m += " an intra CTU waited for a neighbour that never finished";
+    char buf[160];
+    std::snprintf(buf, sizeof(buf), " (entry %d = picture %d CTU table index %d at (%d,%d), dependencies %d, neighbour %d; %d of %d entries drawn);",
+                  c->error_host[2], c->error_host[3] >> 16, c->error_host[3] & 0xffff, c->error_host[7] & 255, (c->error_host[7] >> 8) & 255,
+                  c->error_host[7] >> 16, c->error_host[4], c->error_host[5], c->error_host[6]);
+    m += buf;
+  }
+  return fail(c, m);
+}
+
 // Copy device planes of `p` into int16 host planes.
 int download_planes(hevcrecon_ctx *c, const DevPicture &p, int16_t *y, int16_t *cb, int16_t *cr, int stride_y, int stride_c) {
   const SeqInfo &s = c->si;
@@ -325,6 +364,7 @@ int download_planes(hevcrecon_ctx *c, const DevPicture &p, int16_t *y, int16_t *
   HIPCHK(c, hipMemcpy2DAsync(h + ny, s.cw * pb, p.p[1], s.stride_c * pb, s.cw * pb, s.ch, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpy2DAsync(h + ny + nc, s.cw * pb, p.p[2], s.stride_c * pb, s.cw * pb, s.ch, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (check_device_errors(c)) return 1;
   int16_t *dst[3] = {y, cb, cr};
   const char *src[3] = {h, h + ny, h + ny + nc};
   for (int k = 0; k < 3; k++) {
@@ -341,6 +381,49 @@ int download_planes(hevcrecon_ctx *c, const DevPicture &p, int16_t *y, int16_t *
     }
   }
   return 0;
+}
+
+// Frees whatever a context holds; also the way out of a hevcrecon_create that failed half-way (every member is
+// either null or valid).
+void destroy_context(hevcrecon_ctx *c) {
+  hipSetDevice(c->device);
+  if (std::getenv("HEVCRECON_DEBUG")) std::fprintf(stderr, "hevcrecon: longest wait of an intra CTU for a neighbour: %d polls\n", c->longest_intra_wait);
+  // nothing may still be using the buffers freed below: the kernels' stream first, then the copy streams the
+  // contexts of this device share (they read the pinned upload ring and write its device mirror)
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->have_copy_streams)
+    for (int i = 0; i < kCopyStreams; i++) hipStreamSynchronize(c->copy_stream[i]);
+  drain_intervals(c);
+  for (size_t i = 0; i < c->pics.size(); i++) free_picture(c->pics[i]);
+  for (size_t i = 0; i < c->work.size(); i++) free_picture(c->work[i]);
+  for (size_t i = 0; i < c->work_resi.size(); i++) {
+    if (c->work_resi[i]) hipFree(c->work_resi[i]);
+    c->work_resi[i] = nullptr;
+  }
+  free_picture(c->stage[0]);
+  free_picture(c->stage[1]);
+  for (size_t i = 0; i < c->event_pool.size(); i++) hipEventDestroy(c->event_pool[i]);
+  for (int i = 0; i < kRing; i++)
+    if (c->ring_ev[i]) hipEventDestroy(c->ring_ev[i]);
+  for (int i = 0; i < kRing; i++)
+    if (c->batch_ev[i]) hipEventDestroy(c->batch_ev[i]);
+  for (int i = 0; i < kRing * kCopyStreams; i++)
+    if (c->copy_ev[i]) hipEventDestroy(c->copy_ev[i]);
+  if (c->jobs_host) hipHostFree(c->jobs_host);
+  if (c->jobs_dev) hipFree(c->jobs_dev);
+  if (c->sync_dev) hipFree(c->sync_dev);
+  if (c->list_host) hipHostFree(c->list_host);
+  if (c->list_dev) hipFree(c->list_dev);
+  if (c->error_flag_dev) hipFree(c->error_flag_dev);
+  if (c->error_host) hipHostFree(c->error_host);
+  if (c->dl_host) hipHostFree(c->dl_host);
+  if (c->out_dev) hipFree(c->out_dev);
+  if (c->up_host) hipHostFree(c->up_host);
+  if (c->up_dev) hipFree(c->up_dev);
+  if (c->stream) hipStreamDestroy(c->stream);
+  if (c->have_copy_streams) release_copy_streams(c->device);
+  (void)hipGetLastError();
+  delete c;
 }
 
 }  // namespace
@@ -367,50 +450,23 @@ extern "C" int hevcrecon_create(hevcrecon_ctx **out, int device) {
   ok = ok && hipMalloc((void **)&c->jobs_dev, sizeof(PicJob) * HR_MAX_BATCH * kRing) == hipSuccess;
 
   ok = ok && hipMalloc((void **)&c->error_flag_dev, 64) == hipSuccess;
+  ok = ok && hipHostMalloc((void **)&c->error_host, 64) == hipSuccess;
   for (int i = 0; ok && i < kRing; i++) ok = hipEventCreate(&c->ring_ev[i]) == hipSuccess;
   for (int i = 0; ok && i < kRing; i++) ok = hipEventCreateWithFlags(&c->batch_ev[i], hipEventDisableTiming) == hipSuccess;
   for (int i = 0; ok && i < kRing * kCopyStreams; i++) ok = hipEventCreateWithFlags(&c->copy_ev[i], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipMemsetAsync(c->error_flag_dev, 0, 64, c->stream) == hipSuccess;
   if (!ok) {
-    if (c->have_copy_streams) release_copy_streams(device);
-    delete c;
+    (void)hipGetLastError();
+    destroy_context(c);
     return 3;
   }
-  hipMemsetAsync(c->error_flag_dev, 0, 64, c->stream);
   *out = c;
   return 0;
 }
 
 extern "C" void hevcrecon_destroy(hevcrecon_ctx *c) {
   if (!c) return;
-  hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
-  drain_intervals(c);
-  for (size_t i = 0; i < c->pics.size(); i++) free_picture(c->pics[i]);
-  for (size_t i = 0; i < c->work.size(); i++) free_picture(c->work[i]);
-  for (size_t i = 0; i < c->work_resi.size(); i++) {
-    if (c->work_resi[i]) hipFree(c->work_resi[i]);
-    c->work_resi[i] = nullptr;
-  }
-  free_picture(c->stage[0]);
-  free_picture(c->stage[1]);
-  for (size_t i = 0; i < c->event_pool.size(); i++) hipEventDestroy(c->event_pool[i]);
-  for (int i = 0; i < kRing; i++) hipEventDestroy(c->ring_ev[i]);
-  for (int i = 0; i < kRing; i++) hipEventDestroy(c->batch_ev[i]);
-  for (int i = 0; i < kRing * kCopyStreams; i++) hipEventDestroy(c->copy_ev[i]);
-  if (c->jobs_host) hipHostFree(c->jobs_host);
-  if (c->jobs_dev) hipFree(c->jobs_dev);
-
-  if (c->error_flag_dev) hipFree(c->error_flag_dev);
-  if (c->dl_host) hipHostFree(c->dl_host);
-  if (c->out_dev) hipFree(c->out_dev);
-  if (c->up_host) hipHostFree(c->up_host);
-  if (c->up_dev) hipFree(c->up_dev);
-  hipStreamDestroy(c->stream);
-  if (c->have_copy_streams) {
-    for (int i = 0; i < kCopyStreams; i++) hipStreamSynchronize(c->copy_stream[i]);
-    release_copy_streams(c->device);
-  }
-  delete c;
+  destroy_context(c);
 }
 
 extern "C" int hevcrecon_set_upload_ring(hevcrecon_ctx *c, int64_t bytes) {
@@ -720,13 +776,27 @@ extern "C" int64_t hevcrecon_syntax_algorithmic_bytes(const hevcrecon_syntax *s)
 // ---------------------------------------------------------------------------------------------
 // reconstruction
 // ---------------------------------------------------------------------------------------------
-extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, const int *dst_ids) {
-  if (!c || !syn || !dst_ids) return 1;
-  if (n <= 0 || n > HR_MAX_BATCH) return fail(c, "batch size must be 1..256");
-  if (!c->have_seq) return fail(c, "no sequence parameters");
-  HIPCHK(c, hipSetDevice(c->device));
+namespace {
+
+// Device memory a batch works in besides the pictures it reads and writes: the job descriptors, per picture of the
+// batch a working picture (prediction, reconstruction and deblocking happen there when SAO is on) and the residual
+// planes of its intra blocks.  hevcrecon_reconstruct_batch takes them from the context's pools, which grow on
+// demand.
+struct WorkSet {
+  PicJob *jobs_host;  // pinned
+  PicJob *jobs_dev;
+  void *work_base[HR_MAX_BATCH];  // working pictures (planes at the context's plane_off)
+  void *resi_base[HR_MAX_BATCH];  // residual planes (at the context's resi_off)
+  uint32_t *sync_dev;             // intra kernel: ticket counter (word 0), "done" words of picture i from word kSyncHead + i * CTUs
+  uint32_t *list_host, *list_dev; // intra kernel: the batch's CTU list (pinned / device); unused for a single picture
+  int slot;                       // entry of the pinned job ring that jobs_host belongs to
+  bool fixed;                     // the allocation-free entry point: no timers, no stage copies
+};
+const size_t kSyncHead = 64;  // words in front of the "done" words (the ticket counter has a 256-byte line of its own)
+
+// Everything the kernels will index with is checked before anything is launched.
+int validate_batch(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, const int *dst_ids) {
   const SeqInfo &s = c->si;
-  // ---- validate everything the kernels will index with, before anything is launched ----
   for (int i = 0; i < n; i++) {
     hevcrecon_syntax *y = syn[i];
     if (!y || y->ctx != c || !y->uploaded || !y->pk.finished) return fail(c, "syntax object not finished on this context");
@@ -746,26 +816,17 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     if (y->pk.inter_without_ref || y->pk.max_ref_idx[0] >= pp.num_ref[0] || y->pk.max_ref_idx[1] >= pp.num_ref[1])
       return fail(c, "motion record refers to a reference index outside the lists");
   }
-  // ---- device pictures ----
-  for (int i = 0; i < n; i++) {
-    if ((int)c->pics.size() <= dst_ids[i]) c->pics.resize(dst_ids[i] + 1);
-    if (alloc_picture(c, c->pics[dst_ids[i]])) return 1;
-  }
-  if ((int)c->work.size() < n) c->work.resize(n);
-  if ((int)c->work_resi.size() < n) c->work_resi.resize(n, nullptr);
-  for (int i = 0; i < n; i++) {
-    if (alloc_picture(c, c->work[i])) return 1;
-    if (!c->work_resi[i]) HIPCHK(c, hipMalloc(&c->work_resi[i], c->resi_bytes));
-  }
-  if (c->keep_stages)
-    for (int k = 0; k < 2; k++)
-      if (alloc_picture(c, c->stage[k])) return 1;
-  // ---- job descriptors ----
-  const int slot = c->ring_pos;
-  c->ring_pos = (c->ring_pos + 1) % kRing;
-  if (c->ring_used[slot]) HIPCHK(c, hipEventSynchronize(c->ring_ev[slot]));
-  PicJob *jh = c->jobs_host + (size_t)slot * HR_MAX_BATCH;
-  PicJob *jd = c->jobs_dev + (size_t)slot * HR_MAX_BATCH;
+  return 0;
+}
+
+// Queues the hand-over of the stale pictures, the job descriptors and the kernels of one batch.  The caller has
+// validated the batch and made sure every destination picture and everything `ws` names exists.  Book-keeping that
+// later calls rely on (which pictures have been copied and expanded, the ring position) is committed only once
+// everything has been queued: after a failure half-way the next call starts from the state before this one.
+int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, const int *dst_ids, const WorkSet &ws) {
+  const SeqInfo &s = c->si;
+  PicJob *jh = ws.jobs_host, *jd = ws.jobs_dev;
+  if (c->ring_used[ws.slot]) HIPCHK(c, hipEventSynchronize(c->ring_ev[ws.slot]));
   int max_tu[4] = {0, 0, 0, 0}, max_levels = 0, max_mct[3] = {0, 0, 0}, max_mcb = 0;
   bool any_deblock = false, any_sao = false, any_wp = false, any_expand = false;
   for (int i = 0; i < n; i++) {
@@ -779,7 +840,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     const bool sao_on = k.pp.sao_luma || k.pp.sao_chroma;
     for (int p = 0; p < 3; p++) {
       j.out[p] = c->pics[dst_ids[i]].p[p];
-      j.rec[p] = sao_on ? c->work[i].p[p] : j.out[p];
+      j.rec[p] = sao_on ? (void *)((char *)ws.work_base[i] + c->plane_off[p]) : j.out[p];
     }
     any_sao = any_sao || sao_on;
     for (int l = 0; l < 2; l++)
@@ -793,7 +854,6 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     j.ctu_run_off = (const uint32_t *)(y->up_dev + y->off_runoff);
     j.need_expand = y->expanded ? 0 : 1;
     any_expand = any_expand || !y->expanded;
-    y->expanded = true;
     for (int t = 0; t < 3; t++) {
       j.mc_tile[t] = (const McTile *)(y->up_dev + y->off_mct[t]);
       j.n_mc_tile[t] = (int)k.mc_tile[t].size();
@@ -808,13 +868,14 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
       if (j.n_tu[t] > max_tu[t]) max_tu[t] = j.n_tu[t];
     }
     j.coeff = (const uint32_t *)(y->up_dev + y->off_coeff);
-    for (int p = 0; p < 3; p++) j.resi[p] = (int16_t *)((char *)c->work_resi[i] + c->resi_off[p]);
+    for (int p = 0; p < 3; p++) j.resi[p] = (int16_t *)((char *)ws.resi_base[i] + c->resi_off[p]);
     j.intra = (const IntraItem *)(y->up_dev + y->off_intra);
     j.ictu = (const IntraCtu *)(y->up_dev + y->off_ictu);
     j.lvl_counts = (const uint16_t *)(y->up_dev + y->off_lvlc);
     j.wave_off = (const int32_t *)(y->up_dev + y->off_wave);
     j.n_waves = k.wave_off.empty() ? 0 : (int)k.wave_off.size() - 1;
     if (j.n_waves > max_levels) max_levels = j.n_waves;
+    j.ctu_done = ws.sync_dev + kSyncHead + (size_t)i * s.ctus_w * s.ctus_h;
     j.sao = (const SaoCtu *)(y->up_dev + y->off_sao);
     j.scaling = k.use_scaling ? (const ScalingTables *)(y->up_dev + y->off_scal) : nullptr;
     j.wp = k.use_wp ? (const WpTables *)(y->up_dev + y->off_wp) : nullptr;
@@ -834,6 +895,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     j.error_flag = c->error_flag_dev;
     any_deblock = any_deblock || !k.pp.deblocking_disable;
   }
+  bool uploaded_any = false;
   {  // hand-over of the pictures whose device copy is stale
     int64_t newest_reader = -1;
     bool any = false;
@@ -867,15 +929,11 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
           run_d = y ? y->up_dev : nullptr;
           run_n = y ? y->upload_bytes : 0;
         }
-        if (y) {
-          y->dirty = false;
-          y->upload_seq = c->upload_no;
-        }
       }
-      c->upload_no++;
+      uploaded_any = true;
     }
     // device copies complete: events behind everything the copy streams hold cover the whole batch
-    bool wait = false;
+    bool wait = uploaded_any;
     for (int i = 0; i < n; i++) wait = wait || syn[i]->upload_seq > c->upload_waited;
     if (wait) {
       for (int k = 0; k < kCopyStreams; k++) {
@@ -884,15 +942,43 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
         HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));
       }
       c->copy_ev_pos = (c->copy_ev_pos + 1) % kRing;
-      c->upload_waited = c->upload_no - 1;
+    }
+  }
+  // The intra kernel takes the whole batch in one launch.  Its CTUs go into a list in which every CTU follows the
+  // ones it reads from: the first waves of all pictures, then their second waves, and so on (a single picture's own
+  // table is in that order already and needs no list).  The list travels with the job descriptors, ahead of the
+  // event that tells the host when this ring slot's pinned memory may be written again.
+  size_t n_intra_ctus = 0;
+  int intra_parallel = 0;  // CTUs of the batch's largest wave
+  const uint32_t *intra_list = nullptr;
+  if (max_levels > 0) {
+    uint32_t *lh = ws.list_host;
+    for (int l = 0; l < max_levels; l++) {
+      int in_wave = 0;
+      for (int i = 0; i < n; i++) {
+        const std::vector<int32_t> &lo = syn[i]->pk.wave_off;
+        if (l + 1 < (int)lo.size()) {
+          in_wave += lo[l + 1] - lo[l];
+          if (n > 1)
+            for (int32_t k = lo[l]; k < lo[l + 1]; k++) lh[n_intra_ctus++] = ((uint32_t)i << 16) | (uint32_t)k;
+        }
+      }
+      intra_parallel = std::max(intra_parallel, in_wave);
+    }
+    if (n == 1) {
+      n_intra_ctus = syn[0]->pk.ictu.size();
+    } else {
+      HIPCHK(c, hipMemcpyAsync(ws.list_dev, lh, n_intra_ctus * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+      intra_list = ws.list_dev;
     }
   }
   HIPCHK(c, hipMemcpyAsync(jd, jh, sizeof(PicJob) * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipEventRecord(c->ring_ev[slot], c->stream));
-  c->ring_used[slot] = true;
+  HIPCHK(c, hipEventRecord(c->ring_ev[ws.slot], c->stream));
+  c->ring_used[ws.slot] = true;
+  const bool stages = c->keep_stages && !ws.fixed;
   // ---- launches ----
   if (any_expand) {
-    Timed tm(c, K_OTHER, 1);
+    Timed tm(c, K_OTHER, 1, !ws.fixed);
     hr_launch(K_OTHER, jd, n, s, c->stream, 0, 0);
   }
   if (max_mct[0] > 0 || max_mct[1] > 0 || max_mct[2] > 0 || max_mcb > 0) {
@@ -901,7 +987,7 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     for (int t = 0; t < 4; t++) {
       const int cnt = t < 3 ? max_mct[t] : max_mcb;
       if (cnt > 0) {
-        Timed tm(c, cls[t], 1);
+        Timed tm(c, cls[t], 1, !ws.fixed);
         hr_launch(K_INTER, jd, n, s, c->stream, t + (any_wp ? 4 : 0), cnt);
       }
     }
@@ -910,62 +996,145 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     int nl = 0;
     for (int t = 0; t < 4; t++) nl += max_tu[t] > 0;
     if (nl) {
-      Timed tm(c, K_TRANSFORM, nl);
+      Timed tm(c, K_TRANSFORM, nl, !ws.fixed);
       for (int t = 0; t < 4; t++)
         if (max_tu[t] > 0) hr_launch(K_TRANSFORM, jd, n, s, c->stream, t + 2, max_tu[t]);
     }
   }
-  if (max_levels > 0) {
-    Timed tm(c, K_INTRA, 0);
-    for (int l = 0; l < max_levels; l++) {
-      int mx = 0;
-      for (int i = 0; i < n; i++) {
-        const std::vector<int32_t> &lo = syn[i]->pk.wave_off;
-        if (l + 1 < (int)lo.size()) mx = std::max(mx, lo[l + 1] - lo[l]);
-      }
-      if (mx > 0) {
-        hr_launch(K_INTRA, jd, n, s, c->stream, l, mx);
-        c->launches[K_INTRA]++;
-      }
-    }
+  if (n_intra_ctus > 0) {
+    HIPCHK(c, hipMemsetAsync(ws.sync_dev, 0, (kSyncHead + (size_t)n * s.ctus_w * s.ctus_h) * sizeof(uint32_t), c->stream));
+    Timed tm(c, K_INTRA, 1, !ws.fixed);
+    hr_launch_intra(jd, s, intra_list, (int)n_intra_ctus, intra_parallel, ws.sync_dev, c->stream);
   }
-  if (c->keep_stages) {
+  if (stages) {
     Timed tm(c, K_COPY, 1);
     HIPCHK(c, hipMemcpyAsync(c->stage[0].base, jh[0].rec[0], c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
   }
   if (any_deblock) {
     {
-      Timed tm(c, K_DEBLOCK_V, 1);
+      Timed tm(c, K_DEBLOCK_V, 1, !ws.fixed);
       hr_launch(K_DEBLOCK_V, jd, n, s, c->stream, 0, 0);
     }
     {
-      Timed tm(c, K_DEBLOCK_H, 1);
+      Timed tm(c, K_DEBLOCK_H, 1, !ws.fixed);
       hr_launch(K_DEBLOCK_H, jd, n, s, c->stream, 0, 0);
     }
   }
-  if (c->keep_stages) {
+  if (stages) {
     Timed tm(c, K_COPY, 1);
     HIPCHK(c, hipMemcpyAsync(c->stage[1].base, jh[0].rec[0], c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
   }
   if (any_sao) {
-    Timed tm(c, K_SAO, 1);
+    Timed tm(c, K_SAO, 1, !ws.fixed);
     hr_launch(K_SAO, jd, n, s, c->stream, 0, 0);
   }
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->batch_ev[c->batch_no % kRing], c->stream));
-  for (int i = 0; i < n; i++) syn[i]->last_batch = c->batch_no;
+  // ---- everything is queued: commit ----
+  for (int i = 0; i < n; i++) {
+    hevcrecon_syntax *y = syn[i];
+    if (y->dirty) {
+      y->dirty = false;
+      y->upload_seq = c->upload_no;
+    }
+    y->expanded = true;
+    y->last_batch = c->batch_no;
+  }
+  if (uploaded_any) c->upload_no++;
+  c->upload_waited = c->upload_no - 1;
   c->batch_no++;
   for (int i = 0; i < n; i++) {
     c->pics[dst_ids[i]].valid = true;
     c->pics[dst_ids[i]].poc = syn[i]->pk.pp.poc;
   }
-  if (c->intervals.size() > 4096) drain_intervals(c);
+  if (!ws.fixed && c->intervals.size() > 4096) drain_intervals(c);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, const int *dst_ids) {
+  if (!c || !syn || !dst_ids) return 1;
+  if (n <= 0 || n > HR_MAX_BATCH) return fail(c, "batch size must be 1..256");
+  if (!c->have_seq) return fail(c, "no sequence parameters");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (validate_batch(c, n, syn, dst_ids)) return 1;
+  // ---- device pictures ----
+  for (int i = 0; i < n; i++) {
+    if ((int)c->pics.size() <= dst_ids[i]) c->pics.resize(dst_ids[i] + 1);
+    if (alloc_picture(c, c->pics[dst_ids[i]])) return 1;
+  }
+  if ((int)c->work.size() < n) c->work.resize(n);
+  if ((int)c->work_resi.size() < n) c->work_resi.resize(n, nullptr);
+  for (int i = 0; i < n; i++) {
+    if (alloc_picture(c, c->work[i])) return 1;
+    if (!c->work_resi[i]) HIPCHK(c, hipMalloc(&c->work_resi[i], c->resi_bytes));
+  }
+  if (c->keep_stages)
+    for (int k = 0; k < 2; k++)
+      if (alloc_picture(c, c->stage[k])) return 1;
+  const size_t nctu = (size_t)c->si.ctus_w * c->si.ctus_h;
+  if (c->sync_words < kSyncHead + n * nctu) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->sync_dev) hipFree(c->sync_dev);
+    c->sync_dev = nullptr;
+    c->sync_words = 0;
+    const size_t words = kSyncHead + std::max<size_t>(n, 16) * nctu;
+    HIPCHK(c, hipMalloc((void **)&c->sync_dev, words * sizeof(uint32_t)));
+    c->sync_words = words;
+  }
+  if (n > 1 && c->list_cap < n * nctu) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->list_host) hipHostFree(c->list_host);
+    if (c->list_dev) hipFree(c->list_dev);
+    c->list_host = c->list_dev = nullptr;
+    c->list_cap = 0;
+    const size_t cap = std::max<size_t>(n, 16) * nctu;
+    HIPCHK(c, hipHostMalloc((void **)&c->list_host, cap * kRing * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->list_dev, cap * kRing * sizeof(uint32_t)));
+    c->list_cap = cap;
+  }
+  WorkSet ws;
+  ws.slot = c->ring_pos;
+  ws.jobs_host = c->jobs_host + (size_t)ws.slot * HR_MAX_BATCH;
+  ws.jobs_dev = c->jobs_dev + (size_t)ws.slot * HR_MAX_BATCH;
+  ws.sync_dev = c->sync_dev;
+  ws.list_host = c->list_host + (size_t)ws.slot * c->list_cap;
+  ws.list_dev = c->list_dev + (size_t)ws.slot * c->list_cap;
+  ws.fixed = false;
+  for (int i = 0; i < n; i++) {
+    ws.work_base[i] = c->work[i].base;
+    ws.resi_base[i] = c->work_resi[i];
+  }
+  if (int rc = reconstruct_core(c, n, syn, dst_ids, ws)) return rc;
+  c->ring_pos = (c->ring_pos + 1) % kRing;
   return 0;
 }
 
 extern "C" int hevcrecon_reconstruct(hevcrecon_ctx *c, hevcrecon_syntax *syn, int dst_pic_id) {
   hevcrecon_syntax *one[1] = {syn};
   return hevcrecon_reconstruct_batch(c, 1, one, &dst_pic_id);
+}
+
+// TDecTop::xCreateLostPicture (TLibDecoder/TDecTop.cpp:214-261) conceals a lost reference with a copy of the
+// nearest picture (TComPicYuv::copyToPic, :244): here a device-to-device copy, queued behind the kernels that
+// write the source.
+extern "C" int hevcrecon_picture_copy(hevcrecon_ctx *c, int dst_pic_id, int src_pic_id, int dst_poc) {
+  if (!c) return 1;
+  if (!c->have_seq) return fail(c, "no sequence parameters");
+  if (src_pic_id < 0 || src_pic_id >= (int)c->pics.size() || !c->pics[src_pic_id].valid) return fail(c, "source picture is not resident");
+  if (dst_pic_id < 0 || dst_pic_id >= kMaxPics) return fail(c, "picture id out of range");
+  if (dst_pic_id == src_pic_id) {
+    c->pics[dst_pic_id].poc = dst_poc;
+    return 0;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  if ((int)c->pics.size() <= dst_pic_id) c->pics.resize(dst_pic_id + 1);
+  if (alloc_picture(c, c->pics[dst_pic_id])) return 1;
+  HIPCHK(c, hipMemcpyAsync(c->pics[dst_pic_id].base, c->pics[src_pic_id].base, c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
+  c->pics[dst_pic_id].valid = true;
+  c->pics[dst_pic_id].poc = dst_poc;
+  return 0;
 }
 
 extern "C" int hevcrecon_picture_download(hevcrecon_ctx *c, int pic_id, int16_t *y, int16_t *cb, int16_t *cr, int stride_y,
@@ -1114,7 +1283,7 @@ extern "C" int hevcrecon_synchronize(hevcrecon_ctx *c) {
   for (int k = 0; k < kCopyStreams; k++) HIPCHK(c, hipStreamSynchronize(c->copy_stream[k]));
   c->upload_synced = c->upload_no - 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  return check_device_errors(c);
 }
 
 // ---------------------------------------------------------------------------------------------

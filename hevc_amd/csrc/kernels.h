@@ -5,9 +5,17 @@
 
 // Launches kernel class `kind` (K_* of common.h) for a batch of `n` pictures described by the device
 // array `jobs`.  arg/arg2: K_TRANSFORM: log2 block size, max blocks of that size over the batch;
-// K_INTRA: CTU wave, max CTUs of that wave over the batch.  K_OTHER: expansion of the run-length coded motion
+// K_OTHER: expansion of the run-length coded motion
 // records of the pictures whose need_expand is set.
 void hr_launch(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t stream, int arg, int arg2);
+
+// Intra prediction + residual of a batch, one launch: `list` holds n_items entries (picture of the batch << 16 |
+// index into that picture's ictu[]) in an order in which every CTU follows the CTUs it reads from, or is NULL for
+// a single picture (its ictu[] is in such an order already).  `ticket` and every picture's ctu_done words must be
+// zero when the kernel starts.
+// max_parallel: the most CTUs that can be in work at a time (the batch's largest wave).
+void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list, int n_items, int max_parallel, unsigned *ticket,
+                     hipStream_t stream);
 
 // Converts picture planes to the bytes TVideoIOYuv::write puts into a file: width x height samples of each plane
 // (chroma: half of each), `file_bd` bits deep (scaled from the internal depth with rounding and clipping, or shifted

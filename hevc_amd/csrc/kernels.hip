@@ -19,6 +19,7 @@
 #else
 #include <hip/hip_runtime.h>
 #endif
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -56,6 +57,46 @@ __device__ __forceinline__ unsigned hr_brev(unsigned v) { return __brev(v); }
 
 template <typename pel_t>
 __device__ __forceinline__ const pel_t *plane_c(const void *p) { return (const pel_t *)p; }
+
+// Hand-over of data between workgroups of ONE launch (the intra kernel's CTUs).  The L1 of a compute unit is never
+// refreshed by another unit's stores and plain stores may sit in the L2 of their chiplet, so:
+//   producer  write-through stores (hr_store_through) -> every storing wave waits for its stores (hr_drain_stores)
+//             -> workgroup barrier -> one lane raises the flag (hr_flag_raise)
+//   consumer  one lane polls the flag (hr_flag_read, L1 bypassed) -> hr_acquire (drops this unit's L1 lines)
+//             -> workgroup barrier -> plain loads
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ unsigned hr_ticket_take(unsigned *p) { return __atomic_fetch_add(p, 1u, __ATOMIC_RELAXED); }
+__device__ __forceinline__ unsigned hr_flag_read(const unsigned *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+__device__ __forceinline__ void hr_flag_raise(unsigned *p) { __atomic_store_n(p, 1u, __ATOMIC_RELEASE); }
+__device__ __forceinline__ void hr_store_through(unsigned long long *p, unsigned long long v) { *p = v; }
+__device__ __forceinline__ void hr_drain_stores() {}
+__device__ __forceinline__ void hr_acquire() {}
+__device__ __forceinline__ void hr_nap() {}
+__device__ __forceinline__ unsigned long long hr_clock100() { return 0; }
+#else
+// Every shared word is accessed through a GLOBAL (address space 1) pointer at agent scope: pointers that kernels load
+// from memory are generic, and generic (flat) accesses neither bypass the L1 reliably nor order like global ones.
+typedef __attribute__((address_space(1))) unsigned hr_gu32;
+typedef __attribute__((address_space(1))) unsigned long long hr_gu64;
+__device__ __forceinline__ unsigned hr_ticket_take(unsigned *p) {
+  return __hip_atomic_fetch_add((hr_gu32 *)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned hr_flag_read(const unsigned *p) {
+  return __hip_atomic_load((const hr_gu32 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hr_flag_raise(unsigned *p) { __hip_atomic_store((hr_gu32 *)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void hr_store_through(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store((hr_gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void hr_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void hr_acquire() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// constant 100 MHz clock, for bounding waits by time rather than by iterations
+__device__ __forceinline__ unsigned long long hr_clock100() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void hr_nap() { __builtin_amdgcn_s_sleep(32); }  // ~1 us between polls: waits last tens of them
+#endif
 
 // Core transform matrix of the 32-point inverse DCT: entry (k, i) is round(64*sqrt(2)*cos(pi*k*(2i+1)/64)) as
 // standardised (row 0 is 64); the 16/8/4-point matrices are its rows 2k/4k/8k truncated to their first
@@ -1131,7 +1172,7 @@ tile0[py * tw + px] = (uint16_t)clip3i(0, maxv, v);              \
 #define IT_MAX_LEVELS HR_INTRA_MAX_LEVELS
 
 template <typename pel_t>
-__global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s, int wave_idx) {
+__global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s, const unsigned *list, int n_items, unsigned *ticket) {
   __shared__ uint16_t tile_y[65 * IT_YW];
   __shared__ uint16_t tile_c[2][33 * IT_CW];
   __shared__ int16_t resi_y[64 * 64];
@@ -1140,13 +1181,63 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
   __shared__ uint16_t lvlc_s[IT_MAX_LEVELS];
   __shared__ int ref_s[IT_WAVES][132], flt_s[IT_WAVES][132];
   __shared__ unsigned blk_s[IT_WAVES][4];  // per block of the round: item words 0 and 1, filtered?, DC value
-  const PicJob &J = jobs[blockIdx.y];
-  if (wave_idx >= J.n_waves) return;
-  const int first_ctu = J.wave_off[wave_idx];
-  if ((int)blockIdx.x >= J.wave_off[wave_idx + 1] - first_ctu) return;
-  const IntraCtu ci = J.ictu[first_ctu + blockIdx.x];
+  __shared__ unsigned ticket_s;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  // One launch per batch.  The batch's CTUs (those holding intra blocks) stand in a list ordered so that every CTU
+  // comes after the CTUs it reads from (all pictures' first waves, then their second waves, ...; for a single
+  // picture the order of its own table, list = NULL).  Workgroups draw the next entry until the list is exhausted
+  // and wait, per CTU, for the neighbouring CTUs it depends on.  Whatever the number of workgroups resident at a
+  // time, the earliest unfinished entry never waits for an entry that has not been drawn, so the launch drains.
+  for (;;) {
+  __syncthreads();  // the previous CTU's tile has been written back by every wave
+  if (tid == 0) ticket_s = hr_ticket_take(ticket);
+  __syncthreads();
+  const unsigned entry_idx = ticket_s;
+  if (entry_idx >= (unsigned)n_items) break;
+  const unsigned entry = list ? list[entry_idx] : entry_idx;
+  const PicJob &J = jobs[entry >> 16];
+  const IntraCtu ci = J.ictu[entry & 0xffffu];
   const int ctux = ci.cx * 64, ctuy = ci.cy * 64;
+  if (tid == 0) {
+    if (ci.n_items > IT_MAX_ITEMS || ci.n_lvl > IT_MAX_LEVELS) atomicOr(J.error_flag, HR_ERR_INTRA_CAPACITY);
+    if (ci.deps) {
+      // the neighbouring CTUs whose intra blocks this one reads: left, above-left, above, above-right
+      const unsigned *done = J.ctu_done + (size_t)ci.cy * s.ctus_w + ci.cx;
+      const int at[4] = {-1, -s.ctus_w - 1, -s.ctus_w, -s.ctus_w + 1};
+      bool timed_out = false;
+      unsigned spins = 0;
+      unsigned long long t0 = 0;
+#pragma unroll
+      for (int d = 0; d < 4; d++)
+        if (ci.deps & (1 << d)) {
+          while (hr_flag_read(done + at[d]) == 0) {
+            // Bounded: after 20 s without progress (or, where there is no clock, 2^26 polls) the neighbour is taken
+            // never to finish (a corrupt list) and the launch gives up instead of hanging.
+            if ((++spins & 0xfff) == 0) {
+              const unsigned long long now = hr_clock100();
+              if (t0 == 0) t0 = now;
+              if (now - t0 > 2000000000ull || spins >= (1u << 26)) {
+                timed_out = true;
+                if (atomicOr(J.error_flag + 1, 1) == 0) {  // first report: which entry waited for which neighbour
+                  J.error_flag[2] = (int)entry_idx;
+                  J.error_flag[3] = (int)entry;
+                  J.error_flag[4] = d;
+                  J.error_flag[5] = (int)hr_flag_read(ticket);
+                  J.error_flag[6] = n_items;
+                  J.error_flag[7] = ci.cx | (ci.cy << 8) | (ci.deps << 16);
+                }
+                break;
+              }
+            }
+            hr_nap();
+          }
+        }
+      if (spins > 4096) atomicMax(J.error_flag + 8, (int)spins);  // longest wait of the launch, for tuning the bound
+      if (timed_out) atomicOr(J.error_flag, HR_ERR_INTRA_TIMEOUT);
+      hr_acquire();
+    }
+  }
+  __syncthreads();
 
   // ---- stage the CTU and its top / left borders in LDS ----
   // An all-intra picture writes every sample of the CTU before reading it, so only the borders are needed.
@@ -1417,41 +1508,37 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
     base += cnt;
   }
   // ---- write the CTU back (in P/B pictures the inter samples staged above go back unchanged) ----
+  // Eight bytes per store, written through to memory: a neighbouring CTU may be waiting for these samples in another
+  // workgroup of this launch.  (Picture widths are multiples of 8 luma samples; a chroma store that begins inside
+  // the picture may end in the row's padding.)
   {
+    constexpr int SPS = 8 / sizeof(pel_t);  // samples per store
+    auto pack8 = [](const uint16_t *t) -> unsigned long long {
+      if constexpr (sizeof(pel_t) == 1)
+        return (unsigned long long)pack4(t[0], t[1], t[2], t[3]) | ((unsigned long long)pack4(t[4], t[5], t[6], t[7]) << 32);
+      else
+        return (unsigned long long)t[0] | ((unsigned long long)t[1] << 16) | ((unsigned long long)t[2] << 32) | ((unsigned long long)t[3] << 48);
+    };
     pel_t *py = (pel_t *)J.rec[0];
-    for (int i = tid; i < 64 * 64 / 4; i += IT_NTHR) {
-      const int ty = i >> 4, tx = (i & 15) * 4;
+    for (int i = tid; i < 64 * 64 / SPS; i += IT_NTHR) {
+      const int ty = i / (64 / SPS), tx = (i % (64 / SPS)) * SPS;
       const int gx = ctux + tx, gy = ctuy + ty;
-      if (gx < s.w && gy < s.h) {
-        const uint16_t *t = &tile_y[(ty + 1) * IT_YW + tx + 1];
-        pel_t *o = py + (size_t)gy * s.stride_y + gx;
-        if constexpr (sizeof(pel_t) == 1) {
-          *(unsigned *)o = pack4(t[0], t[1], t[2], t[3]);
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; k++) o[k] = (pel_t)t[k];
-        }
-      }
+      if (gx < s.w && gy < s.h) hr_store_through((unsigned long long *)(py + (size_t)gy * s.stride_y + gx), pack8(&tile_y[(ty + 1) * IT_YW + tx + 1]));
     }
 #pragma unroll
     for (int c = 0; c < 2; c++) {
       pel_t *pc = (pel_t *)J.rec[1 + c];
-      for (int i = tid; i < 32 * 32 / 4; i += IT_NTHR) {
-        const int ty = i >> 3, tx = (i & 7) * 4;
+      for (int i = tid; i < 32 * 32 / SPS; i += IT_NTHR) {
+        const int ty = i / (32 / SPS), tx = (i % (32 / SPS)) * SPS;
         const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
-        if (gx < s.cw && gy < s.ch) {
-          const uint16_t *t = &tile_c[c][(ty + 1) * IT_CW + tx + 1];
-          pel_t *o = pc + (size_t)gy * s.stride_c + gx;
-          if constexpr (sizeof(pel_t) == 1) {
-            *(unsigned *)o = pack4(t[0], t[1], t[2], t[3]);
-          } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++) o[k] = (pel_t)t[k];
-          }
-        }
+        if (gx < s.cw && gy < s.ch) hr_store_through((unsigned long long *)(pc + (size_t)gy * s.stride_c + gx), pack8(&tile_c[c][(ty + 1) * IT_CW + tx + 1]));
       }
     }
   }
+  hr_drain_stores();
+  __syncthreads();
+  if (tid == 0) hr_flag_raise(J.ctu_done + (size_t)ci.cy * s.ctus_w + ci.cx);
+  }  // next CTU
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1810,7 +1897,10 @@ __global__ __launch_bounds__(256) void k_expand(const PicJob *jobs, SeqInfo s) {
     if (start_s[mid] <= z) lo = mid; else hi = mid - 1;
   }
   Part4 r = runs[first + lo];
-  if (z < r.pad || z > r.pad + r.pad2[0]) return;  // not covered: cannot happen with a well-formed list
+  if (z < r.pad || z > r.pad + r.pad2[0]) {  // not covered: cannot happen with a well-formed list
+    atomicOr(J.error_flag, HR_ERR_EXPAND);
+    return;
+  }
   r.pad = 0;
   r.pad2[0] = 0;
   rec4[(size_t)uy * s.uw + ux] = r;
@@ -1932,10 +2022,6 @@ static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, 
       if (arg == 5) LAUNCH((k_transform<pel_t, 5>), g, dim3(256), st, jobs, s);
       break;
     }
-    case K_INTRA:
-      // arg = CTU wave, arg2 = max number of CTUs in that wave over the batch
-      LAUNCH(k_intra<pel_t>, dim3(arg2, n), dim3(IT_NTHR), st, jobs, s, arg);
-      break;
     case K_OTHER:
       LAUNCH(k_expand, dim3(s.ctus_w * s.ctus_h, n), dim3(256), st, jobs, s);
       break;
@@ -1971,6 +2057,23 @@ void hr_launch_output(const void *const planes[3], void *dst, const SeqInfo &s, 
     }
     out += (size_t)w * h * ws;
   }
+}
+
+void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list, int n_items, int max_parallel, unsigned *ticket, hipStream_t st) {
+  // No more workgroups than CTUs that can ever be worked on at a time (the largest wave of the batch), and no more
+  // than fill the device a few times over: a workgroup that has drawn a CTU holds its place on the device while
+  // it waits for that CTU's neighbours.
+  int grid = n_items < max_parallel ? n_items : max_parallel;
+  // (measured, 1080p, two engine contexts sharing the device: one workgroup per compute unit reconstructs the random
+  // access stream 4 % faster than three, which crowd out the other context's kernels, and the all-intra stream as fast;
+  // a single context with hundreds of all-intra pictures per batch gains from 768: HEVCRECON_INTRA_GRID overrides)
+  static const int cap = std::getenv("HEVCRECON_INTRA_GRID") ? std::atoi(std::getenv("HEVCRECON_INTRA_GRID")) : 256;
+  if (grid > cap) grid = cap;
+  if (grid < 1) grid = 1;
+  if (s.bd_y <= 8 && s.bd_c <= 8)
+    LAUNCH(k_intra<uint8_t>, dim3(grid), dim3(IT_NTHR), st, jobs, s, list, n_items, ticket);
+  else
+    LAUNCH(k_intra<uint16_t>, dim3(grid), dim3(IT_NTHR), st, jobs, s, list, n_items, ticket);
 }
 
 void hr_launch_md5(const Md5Plane *planes, int n, uint8_t *digests, hipStream_t st) {

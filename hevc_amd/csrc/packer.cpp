@@ -97,6 +97,7 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
   ctu_item_nb.clear();
   ctu_item_lvl.clear();
   ctu_dep_wave = 0;
+  ctu_dep_mask = 0;
   const int cx = addr % seq.ctus_w, cy = addr / seq.ctus_w;
   walk_cu(ctu, cx * 64, cy * 64, 0, 0);
   if (!error.empty()) return false;
@@ -115,8 +116,10 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
     ic.lvl_start = (uint32_t)lvl_counts.size();
     ic.n_items = (uint16_t)ctu_items.size();
     ic.n_lvl = (uint16_t)nlev;
-    ic.cx = (uint16_t)cx;
-    ic.cy = (uint16_t)cy;
+    ic.cx = (uint8_t)cx;
+    ic.cy = (uint8_t)cy;
+    ic.deps = (uint8_t)ctu_dep_mask;
+    ic.pad = 0;
     for (int l = 1; l <= nlev; l++) lvl_counts.push_back((uint16_t)start[l + 1]);
     for (int l = 1; l <= nlev + 1; l++) start[l] += start[l - 1];
     intra.resize(ic.item_start + ctu_items.size());
@@ -320,8 +323,12 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
   IntraNeighbours nb = {0, 0, 0};
   auto level_at = [&](int ux, int uy) -> int {
     if ((ux >> 4) == my_cx && (uy >> 4) == my_cy) return lvl[(size_t)uy * seq.uw + ux];
-    if (rec4[(size_t)uy * seq.uw + ux].flags & P4_INTRA)
+    if (rec4[(size_t)uy * seq.uw + ux].flags & P4_INTRA) {
       ctu_dep_wave = std::max<int>(ctu_dep_wave, ctu_wave[(size_t)(uy >> 4) * seq.ctus_w + (ux >> 4)]);
+      // neighbours of a block lie in the CTU to the left, above-left, above or above-right of its own
+      const int dx = (ux >> 4) - my_cx, dy = (uy >> 4) - my_cy;
+      ctu_dep_mask |= dy == 0 ? IC_DEP_LEFT : dx < 0 ? IC_DEP_ABOVE_LEFT : dx == 0 ? IC_DEP_ABOVE : IC_DEP_ABOVE_RIGHT;
+    }
     return 0;
   };
   int level = 0;

@@ -62,6 +62,7 @@ struct PackedPicture {
   std::vector<uint16_t> ctu_wave;     // per CTU: wave (0 = no intra blocks)
   std::vector<uint16_t> ictu_wave;    // parallel to ictu before sorting
   int ctu_dep_wave;                   // highest wave among the CTUs whose intra blocks the CTU being added reads
+  int ctu_dep_mask;                   // which of them (IC_DEP_*)
 
   void begin(const SeqInfo &s);
   bool add_ctu(int addr, const hevcrecon_ctu_syntax *ctu);

@@ -152,6 +152,9 @@ class Engine:
         self._check(self.lib.hevcrecon_picture_upload(self.ctx, pic_id, poc, p[0].ctypes.data, p[1].ctypes.data, p[2].ctypes.data,
                                                       p[0].shape[1], p[1].shape[1]), "hevcrecon_picture_upload")
 
+    def copy_picture(self, dst_pic_id, src_pic_id, dst_poc):
+        self._check(self.lib.hevcrecon_picture_copy(self.ctx, dst_pic_id, src_pic_id, dst_poc), "hevcrecon_picture_copy")
+
     def release(self, pic_id):
         self._check(self.lib.hevcrecon_picture_release(self.ctx, pic_id), "hevcrecon_picture_release")
 

@@ -174,6 +174,8 @@ int hevcrecon_sequence_init(hevcrecon_ctx *ctx, const hevcrecon_seq_params *sp);
 
 /* ---- per-picture syntax ------------------------------------------------ */
 
+/* A syntax object belongs to the context it was created on and must be destroyed before that context
+ * (hevcrecon_syntax_destroy waits for the context's streams and gives its space in the upload ring back). */
 int hevcrecon_syntax_create(hevcrecon_ctx *ctx, hevcrecon_syntax **out);
 void hevcrecon_syntax_destroy(hevcrecon_syntax *syn);
 
@@ -223,8 +225,10 @@ int hevcrecon_syntax_finish(hevcrecon_syntax *syn, const hevcrecon_pic_params *p
 
 /* No counterpart in the reference.  Marks an already finished picture for another trip to the device
  * (hevcrecon_syntax_finish marks it once): for hosts that keep packed pictures around, and for measuring the
- * hand-over.  The pictures of a batch that are so marked cross the host link when the batch is submitted: one
- * kernel on a stream of its own reads their pinned buffers, beside the kernels of the batches queued before. */
+ * hand-over.  The pictures of a batch that are so marked cross the host link when the batch is submitted: copy
+ * commands from their pinned staging (pictures that lie back to back in the context's upload ring share one command,
+ * cut into pieces of a few megabytes) spread over three copy streams that the contexts of a device share, beside
+ * the kernels of the batches queued before; the batch's kernels wait for them once. */
 int hevcrecon_syntax_upload(hevcrecon_syntax *syn);
 int hevcrecon_syntax_upload_batch(int n, hevcrecon_syntax *const *syn);
 
@@ -274,9 +278,16 @@ int hevcrecon_debug_download_stage(hevcrecon_ctx *ctx, int stage, int16_t *y, in
 int hevcrecon_picture_upload(hevcrecon_ctx *ctx, int pic_id, int poc, const int16_t *y, const int16_t *cb,
                              const int16_t *cr, int stride_y, int stride_c);
 
+/* Replaces the picture copy in TDecTop::xCreateLostPicture (TLibDecoder/TDecTop.cpp:214-261; TComPicYuv::copyToPic,
+ * :244), which conceals a lost reference with the nearest picture: picture `dst_pic_id` (created or overwritten)
+ * becomes a copy of the resident picture `src_pic_id` and takes the POC `dst_poc`.  Device to device, asynchronous. */
+int hevcrecon_picture_copy(hevcrecon_ctx *ctx, int dst_pic_id, int src_pic_id, int dst_poc);
+
 /* Frees the device picture (TComPic buffers being destroyed: TLibDecoder/TDecTop.cpp:98-118). */
 int hevcrecon_picture_release(hevcrecon_ctx *ctx, int pic_id);
 
+/* Waits for everything queued on the context.  Also the place (with hevcrecon_picture_download) where a work list
+ * that a kernel refused is reported: non-zero, message in hevcrecon_last_error. */
 int hevcrecon_synchronize(hevcrecon_ctx *ctx);
 
 /* ---- measurement ------------------------------------------------------- */

@@ -33,6 +33,8 @@
 #define __shared__ static
 #define __constant__ static const
 #define __launch_bounds__(...)
+#define __align__(n) __attribute__((aligned(n)))
+#define HIP_SYMBOL(x) x
 #define __restrict__
 
 struct dim3 {
@@ -123,6 +125,12 @@ inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 inline int __mul24(int a, int b) { return a * b; }
+inline int atomicOr(int *p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+inline int atomicMax(int *p, int v) {
+  int old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
 inline int min(int a, int b) { return a < b ? a : b; }
 inline int max(int a, int b) { return a > b ? a : b; }
 
@@ -142,6 +150,7 @@ inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp,
   for (size_t y = 0; y < h; y++) std::memcpy((char *)d + y * dp, (const char *)s + y * sp, w);
   return hipSuccess;
 }
+template <typename T> inline hipError_t hipGetSymbolAddress(void **p, T &symbol) { *p = (void *)&symbol; return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

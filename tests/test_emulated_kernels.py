@@ -129,3 +129,132 @@ def _ring_sizes_give_the_same_pictures(lib, ring_bytes):
 @pytest.mark.parametrize("ring_bytes", [48 << 10])  # 48 KB: overflow, then wrap-around at the last picture (more sizes in the GPU suite)
 def test_emulated_upload_ring(emu_lib, ring_bytes):
     _ring_sizes_give_the_same_pictures(emu_lib, ring_bytes)
+
+
+def _clone_with_id_offset(pic, off):
+    """A copy of a picture's syntax whose own id and reference ids are shifted by `off` (a second stream's DPB)."""
+    import copy
+
+    p = copy.copy(pic)
+    p._keep = None
+    p.pic_id = pic.pic_id + off
+    p.pic_params = type(pic.pic_params).from_buffer_copy(pic.pic_params)
+    for l in range(2):
+        for r in range(p.pic_params.num_ref[l]):
+            p.pic_params.ref_pic_id[l][r] = pic.pic_params.ref_pic_id[l][r] + off
+    return p
+
+
+def _heterogeneous_batches_match_their_own_streams(lib, streams, npics, check_stages):
+    """Different streams at DIFFERENT picture positions in one hevcrecon_reconstruct_batch call: I next to P next to B
+    pictures, SAO on next to SAO off, explicit weights next to none, different numbers of intra CTU waves and list
+    sizes.  Stream k starts k batches late, so every batch mixes positions.  Every picture is checked against the
+    digests of the reference decoder's own picture (final; with `check_stages` also before / after deblocking for the
+    first picture of the batch, the one whose stages the engine keeps)."""
+    from hevc_amd import syntax
+
+    seqs = [load_golden(name + "_416x240", npics) for name in streams]
+    sp = seqs[0].seq_params
+    for q in seqs:
+        assert bytes(q.seq_params) == bytes(sp), "streams of one batch share the sequence parameters"
+    bd = [sp.bit_depth_luma, sp.bit_depth_chroma, sp.bit_depth_chroma]
+    eng = engine.Engine(sp, lib=lib)
+    eng.keep_stages(check_stages)
+    n = len(seqs)
+    syns = [eng.new_syntax() for _ in range(n)]
+    steps = max(len(q.pictures) for q in seqs) + n - 1
+    kinds = set()
+    for b in range(steps):
+        members = [(k, b - k) for k in range(n) if 0 <= b - k < len(seqs[k].pictures)]
+        # rotate so that a different stream comes first (and has its stages kept) in every batch
+        members = members[b % len(members):] + members[:b % len(members)]
+        pics = [_clone_with_id_offset(seqs[k].pictures[t], 64 * k) for k, t in members]
+        for (k, t), p in zip(members, pics):
+            syns[k].pack(p)
+        kinds.add(tuple(sorted({int(p.pic_params.slice_type) for p in pics})))
+        eng.reconstruct_batch([syns[k] for k, _ in members], [p.pic_id for p in pics])
+        for i, ((k, t), p) in enumerate(zip(members, pics)):
+            final = eng.download(p.pic_id)
+            assert [syntax.plane_md5(final[c], bd[c]) for c in range(3)] == p.stage_md5[2], (streams[k], p.poc, "final")
+            if check_stages and i == 0:
+                for stage in range(2):
+                    got = eng.download_stage(stage)
+                    assert [syntax.plane_md5(got[c], bd[c]) for c in range(3)] == p.stage_md5[stage], (streams[k], p.poc, stage)
+    assert any(len(kk) > 1 for kk in kinds), "no batch mixed slice types"
+    for y in syns:
+        y.close()
+    eng.close()
+
+
+def test_emulated_heterogeneous_batch(emu_lib):
+    _heterogeneous_batches_match_their_own_streams(emu_lib, ["lowdelay_P_main", "wpp", "intra_main", "slices"], 3, True)
+
+
+def _picture_copy_gives_the_same_picture(lib):
+    seq = load_golden("lowdelay_P_main_416x240", 2)
+    eng = engine.Engine(seq.seq_params, lib=lib)
+    syn = eng.new_syntax()
+    pic = seq.pictures[0]
+    syn.pack(pic)
+    eng.reconstruct(syn, pic.pic_id)
+    eng.copy_picture(40, pic.pic_id, 77)
+    a, b = eng.download(pic.pic_id), eng.download(40)
+    for c in range(3):
+        assert np.array_equal(a[c], b[c])
+    # the copy serves as a reference like any other picture: the P picture predicted from it equals the original
+    p1 = _clone_with_id_offset(seq.pictures[1], 0)
+    for l in range(2):
+        for r in range(p1.pic_params.num_ref[l]):
+            p1.pic_params.ref_pic_id[l][r] = 40
+    syn.pack(p1)
+    eng.reconstruct(syn, 41)
+    assert eng.md5([41]) == [seq.pictures[1].stage_md5[2]]
+    with pytest.raises(engine.EngineError):
+        eng.copy_picture(42, 999, 0)
+    syn.close()
+    eng.close()
+
+
+def test_emulated_picture_copy(emu_lib):
+    _picture_copy_gives_the_same_picture(emu_lib)
+
+
+def _synthetic_dc_picture(sp):
+    """A picture made up here, not decoded: every CTU split into 32x32 intra coding units predicted with the DC mode,
+    no residual, SAO off.  With no neighbours available anywhere before the first block, every sample comes out as
+    1 << (bit depth - 1): a known answer that needs no reference decoder."""
+    from hevc_amd import syntax
+
+    P = abi.PARTS_PER_CTU
+    nctu = ((sp.width + 63) // 64) * ((sp.height + 63) // 64)
+    pic = syntax.PictureSyntax()
+    pic.nctu, pic.pic_id = nctu, 0
+    z = lambda dt, per=1: np.zeros((nctu, P * per), dt)
+    pic.a = {"depth": z(np.uint8) + 1, "pred_mode": z(np.int8) + 1, "part_size": z(np.int8), "tr_idx": z(np.uint8),
+             "cbf0": z(np.uint8), "cbf1": z(np.uint8), "cbf2": z(np.uint8), "qp": z(np.int8) + 30,
+             "luma_dir": z(np.uint8) + 1, "chroma_dir": z(np.uint8) + 1,
+             "tskip0": z(np.uint8), "tskip1": z(np.uint8), "tskip2": z(np.uint8),
+             "mv0": z(np.int16, 2), "mv1": z(np.int16, 2), "ref_idx0": z(np.int8) - 1, "ref_idx1": z(np.int8) - 1,
+             "tq_bypass": z(np.uint8), "ipcm": z(np.uint8),
+             "coeff0": z(np.int16, 16), "coeff1": z(np.int16, 4), "coeff2": z(np.int16, 4)}
+    pic.sao = np.zeros((nctu, 3, 6), np.int32)
+    pic.sao[:, :, 0] = -1
+    pic.pic_params.slice_type = 2
+    pic.pic_params.deblocking_disable = 0
+    return pic
+
+
+def _known_answer_dc_picture(lib, width, height, bit_depth):
+    sp = abi.SeqParams(width=width, height=height, bit_depth_luma=bit_depth, bit_depth_chroma=bit_depth, ctu_size=64, max_cu_depth=4)
+    eng = engine.Engine(sp, lib=lib)
+    syn = eng.new_syntax().pack(_synthetic_dc_picture(sp))
+    eng.reconstruct(syn, 0)
+    for plane in eng.download(0):
+        assert (plane == 1 << (bit_depth - 1)).all()
+    return eng, syn
+
+
+def test_emulated_known_answer_dc_picture(emu_lib):
+    eng, syn = _known_answer_dc_picture(emu_lib, 136, 72, 10)  # sizes that are not multiples of the CTU
+    syn.close()
+    eng.close()

@@ -257,3 +257,40 @@ def test_bench_two_ranks_share_one_gpu_over_gloo():
                     env={"HEVCRECON_BENCH_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
 
+
+@pytest.mark.gpu
+def test_bench_starts_two_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` as the driver runs it: the script starts its two ranks itself; here both share the one
+    GPU of the test machine over gloo.  64 streams over 8 GPUs = 8 per GPU is `--gpus 8 --total-streams 64`."""
+    d = _bench_line(["bench.py", "--gpus", "2", "--total-streams", "5", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                    env={"HEVCRECON_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["streams_per_gpu"] == 3  # rank 0 owns streams 0, 2, 4
+
+
+def test_heterogeneous_batches():
+    """Different streams at different picture positions in one batch (see the helper); two groups because a batch
+    shares its sequence parameters: 8-bit (I / P / B, explicit weights in P slices, slices, tiles, constrained intra,
+    scaling lists) and 10-bit (B slices with and without explicit weights)."""
+    from test_emulated_kernels import _heterogeneous_batches_match_their_own_streams
+    from hevc_amd import abi
+
+    lib = abi.load_library()
+    _heterogeneous_batches_match_their_own_streams(lib, ["lowdelay_P_main", "randomaccess_main", "intra_main", "wpp", "cip", "slices", "tiles", "scalinglist"], None, True)
+    _heterogeneous_batches_match_their_own_streams(lib, ["randomaccess_he10", "wpb"], None, True)
+
+
+def test_picture_copy():
+    from test_emulated_kernels import _picture_copy_gives_the_same_picture
+    from hevc_amd import abi
+
+    _picture_copy_gives_the_same_picture(abi.load_library())
+
+
+def test_known_answer_dc_picture():
+    from test_emulated_kernels import _known_answer_dc_picture
+    from hevc_amd import abi
+
+    for (w, h, bd) in ((136, 72, 10), (1920, 1080, 8)):
+        eng, syn = _known_answer_dc_picture(abi.load_library(), w, h, bd)
+        syn.close()
+        eng.close()

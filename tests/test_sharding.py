@@ -43,3 +43,22 @@ def test_two_ranks_gloo():
     assert out[0][0] == out[1][0] == 2.0          # max over ranks
     assert out[0][1] == out[1][1] == 64 * 60      # whole-job frame count
     assert out[0][2] == [0, 2, 4] and out[1][2] == [1, 3, 5]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (fresh processes), shards the streams with
+    streams_for_rank and prints one line from rank 0.  --rehearse: the plumbing only, no GPU needed."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--total-streams", "7", "--rehearse"], cwd=root, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    text = out.stdout.decode("latin1")
+    assert out.returncode == 0, text[-2000:]
+    lines = [ln for ln in text.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, text[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["streams_total"] == 7 and d["streams_rank0"] == [0, 2, 4, 6] and d["max_over_ranks"] == 2.0
