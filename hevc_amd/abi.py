@@ -123,6 +123,7 @@ EXPORTS = {
     "hevcrecon_syntax_upload": (C.c_int, [_P]),
     "hevcrecon_syntax_upload_batch": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "hevcrecon_reconstruct": (C.c_int, [_P, _P, C.c_int]),
+    "hevcrecon_reconstruct_noalloc": (C.c_int, [_P, _P, C.c_int]),
     "hevcrecon_reconstruct_batch": (C.c_int, [_P, C.c_int, C.POINTER(_P), C.POINTER(C.c_int)]),
     "hevcrecon_picture_download": (C.c_int, [_P, C.c_int, _I16P, _I16P, _I16P, C.c_int, C.c_int]),
     "hevcrecon_picture_download_file": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]),

@@ -23,7 +23,18 @@
 #include "kernels.h"
 #include "packer.h"
 
+// Fixed work area of hevcrecon_reconstruct_noalloc: job descriptor, working picture and residual planes of ONE
+// picture, for callers that must not allocate.  Every GPU the library runs on holds its own copy of the array, at
+// its own address, until the process ends.  In host code the array's name is only a handle for
+// hipGetSymbolAddress: the address kernels and copies use is the one that call returns (g_scratch_ptr), looked up
+// once per device in hevcrecon_create.
+#define HR_SCRATCH_BYTES ((size_t)16 << 20)
+static __device__ __align__(256) unsigned char scratch[HR_SCRATCH_BYTES];
+
 namespace {
+unsigned char *g_scratch_ptr[64];  // per device; guarded by g_copy_mutex
+const size_t kScratchJobBytes = 4096;    // one PicJob
+const size_t kScratchSyncBytes = 61440;  // the intra kernel's scheduling words (ticket counter + one word per CTU)
 const int kMaxPics = 1 << 16;
 const int kRing = 16;
 // Copy streams.  A copy command costs the copy engine ~10 us whatever its size; pictures are ~0.2 MB, so one stream
@@ -54,6 +65,20 @@ bool acquire_copy_streams(int device, hipStream_t out[kCopyStreams]) {
       }
   g.refs++;
   for (int i = 0; i < kCopyStreams; i++) out[i] = g.s[i];
+  return true;
+}
+
+// Device address of this device's copy of the fixed work area (the device must be current).
+bool lookup_scratch(int device) {
+  if (device < 0 || device >= 64) return false;
+  std::lock_guard<std::mutex> lock(g_copy_mutex);
+  if (g_scratch_ptr[device]) return true;
+  void *p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    return false;
+  }
+  g_scratch_ptr[device] = (unsigned char *)p;
   return true;
 }
 
@@ -444,6 +469,7 @@ extern "C" int hevcrecon_create(hevcrecon_ctx **out, int device) {
   std::memset(c->launches, 0, sizeof(c->launches));
   std::memset(c->ring_used, 0, sizeof(c->ring_used));
   bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+  ok = ok && lookup_scratch(device);
   ok = ok && acquire_copy_streams(device, c->copy_stream);
   c->have_copy_streams = ok;
   ok = ok && hipHostMalloc((void **)&c->jobs_host, sizeof(PicJob) * HR_MAX_BATCH * kRing) == hipSuccess;
@@ -781,7 +807,7 @@ namespace {
 // Device memory a batch works in besides the pictures it reads and writes: the job descriptors, per picture of the
 // batch a working picture (prediction, reconstruction and deblocking happen there when SAO is on) and the residual
 // planes of its intra blocks.  hevcrecon_reconstruct_batch takes them from the context's pools, which grow on
-// demand.
+// demand; hevcrecon_reconstruct_noalloc from the library's fixed device array.
 struct WorkSet {
   PicJob *jobs_host;  // pinned
   PicJob *jobs_dev;
@@ -1107,6 +1133,39 @@ extern "C" int hevcrecon_reconstruct_batch(hevcrecon_ctx *c, int n, hevcrecon_sy
     ws.resi_base[i] = c->work_resi[i];
   }
   if (int rc = reconstruct_core(c, n, syn, dst_ids, ws)) return rc;
+  c->ring_pos = (c->ring_pos + 1) % kRing;
+  return 0;
+}
+
+// The allocation-free variant of hevcrecon_reconstruct: same validation, same kernels, but job descriptor, working
+// picture and residual planes lie in the library's fixed device array, the destination picture must exist already,
+// and nothing here (or below) calls hipMalloc, hipHostMalloc, hipFree or creates an event.
+extern "C" int hevcrecon_reconstruct_noalloc(hevcrecon_ctx *c, hevcrecon_syntax *syn, int dst_pic_id) {
+  if (!c || !syn) return 1;
+  if (!c->have_seq) return fail(c, "no sequence parameters");
+  HIPCHK(c, hipSetDevice(c->device));
+  hevcrecon_syntax *one[1] = {syn};
+  if (validate_batch(c, 1, one, &dst_pic_id)) return 1;
+  if (dst_pic_id >= (int)c->pics.size() || !c->pics[dst_pic_id].base)
+    return fail(c, "hevcrecon_reconstruct_noalloc allocates nothing: the destination picture must exist already "
+                   "(created by hevcrecon_picture_upload, hevcrecon_picture_copy or an earlier hevcrecon_reconstruct)");
+  const size_t off_work = kScratchJobBytes + kScratchSyncBytes, off_resi = off_work + align_up(c->pic_bytes, 256);
+  if (off_resi + c->resi_bytes > HR_SCRATCH_BYTES || (kSyncHead + (size_t)c->si.ctus_w * c->si.ctus_h) * sizeof(uint32_t) > kScratchSyncBytes)
+    return fail(c, "hevcrecon_reconstruct_noalloc: picture too large for the fixed 16 MiB work area "
+                   "(it holds pictures up to 1920x1088 at any bit depth); use hevcrecon_reconstruct");
+  unsigned char *base = g_scratch_ptr[c->device];
+  if (!base) return fail(c, "the fixed work area was not found on this device");
+  static_assert(sizeof(PicJob) <= kScratchJobBytes, "job descriptor outgrew its place in the fixed work area");
+  WorkSet ws;
+  ws.slot = c->ring_pos;
+  ws.jobs_host = c->jobs_host + (size_t)ws.slot * HR_MAX_BATCH;  // pinned ring allocated by hevcrecon_create
+  ws.jobs_dev = (PicJob *)base;
+  ws.sync_dev = (uint32_t *)(base + kScratchJobBytes);  // zeroed by the call itself before the intra kernel starts
+  ws.list_host = ws.list_dev = nullptr;                 // a single picture needs no list
+  ws.work_base[0] = base + off_work;
+  ws.resi_base[0] = base + off_resi;
+  ws.fixed = true;
+  if (int rc = reconstruct_core(c, 1, one, &dst_pic_id, ws)) return rc;
   c->ring_pos = (c->ring_pos + 1) % kRing;
   return 0;
 }

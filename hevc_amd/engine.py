@@ -89,6 +89,10 @@ class Engine:
     def reconstruct(self, syn, dst_pic_id):
         self._check(self.lib.hevcrecon_reconstruct(self.ctx, syn.h, dst_pic_id), "hevcrecon_reconstruct")
 
+    def reconstruct_noalloc(self, syn, dst_pic_id):
+        """hevcrecon_reconstruct for callers that cannot allocate (the destination picture must exist already)."""
+        self._check(self.lib.hevcrecon_reconstruct_noalloc(self.ctx, syn.h, dst_pic_id), "hevcrecon_reconstruct_noalloc")
+
     def reconstruct_batch(self, syns, dst_pic_ids):
         n = len(syns)
         hs = (C.c_void_p * n)(*[s.h for s in syns])

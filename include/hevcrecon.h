@@ -245,6 +245,21 @@ int hevcrecon_reconstruct(hevcrecon_ctx *ctx, hevcrecon_syntax *syn, int dst_pic
  * stream none of which references another) with one set of kernel launches. */
 int hevcrecon_reconstruct_batch(hevcrecon_ctx *ctx, int n, hevcrecon_syntax *const *syn, const int *dst_pic_ids);
 
+/* No counterpart in the reference.  hevcrecon_reconstruct for callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same validation, same kernels, same result, but the
+ * call allocates nothing on the device or the host: the job descriptor, the working picture, the residual planes and the
+ * intra kernel's scheduling words lie in a fixed 16 MiB array in device memory that belongs to the library (one copy
+ * per GPU, held until the process ends), and per-kernel timers and stage copies are off.
+ *   - the destination picture must exist already (an earlier hevcrecon_reconstruct, hevcrecon_picture_upload or
+ *     hevcrecon_picture_copy with that id created it); `syn` was finished before, which is where its own device
+ *     buffers were allocated;
+ *   - one picture per call, at most 1920x1088 luma samples (any bit depth): larger pictures are refused with a
+ *     message, use hevcrecon_reconstruct for them;
+ *   - every call on a GPU uses that GPU's one array: calls are ordered by the context's stream, but calls from
+ *     different contexts on the same GPU must not overlap (they would race); the array keeps the last call's
+ *     contents, and the call clears what has to start from zero itself. */
+int hevcrecon_reconstruct_noalloc(hevcrecon_ctx *ctx, hevcrecon_syntax *syn, int dst_pic_id);
+
 /* Copies the final picture into TComPicYuv-style planes (Pel = int16; strides in samples)
  * so that calcAndPrintHashStatus (TLibDecoder/TDecGop.cpp:235) and TVideoIOYuv::write keep working.
  * Blocks until the picture is complete. */

@@ -219,6 +219,38 @@ def test_emulated_picture_copy(emu_lib):
     _picture_copy_gives_the_same_picture(emu_lib)
 
 
+def _noalloc_call(lib, eng, syn, dst):
+    return lib.hevcrecon_reconstruct_noalloc(eng.ctx, syn.h, dst)
+
+
+def _noalloc_matches_regular(lib, first, second):
+    """hevcrecon_reconstruct_noalloc against hevcrecon_reconstruct, two calls in a row on the device's one fixed work
+    area, the second with a smaller input: (fixture, index of the picture to reconstruct both ways) each; the
+    pictures before it are reconstructed the regular way so that its references are resident."""
+    for name, idx in (first, second):
+        seq = load_golden(name, idx + 1)
+        eng = engine.Engine(seq.seq_params, lib=lib)
+        syn = eng.new_syntax()
+        for pic in seq.pictures[:idx]:
+            syn.pack(pic)
+            eng.reconstruct(syn, pic.pic_id)
+        pic = seq.pictures[idx]
+        syn.pack(pic)
+        eng.reconstruct(syn, pic.pic_id)
+        want = eng.download(pic.pic_id)
+        assert eng.md5([pic.pic_id]) == [pic.stage_md5[2]]
+        dst = 50
+        assert _noalloc_call(lib, eng, syn, dst) != 0, "a destination that does not exist yet must be refused"
+        eng.upload(dst, 0, [np.full_like(p, 3) for p in want])  # creates the destination picture
+        assert _noalloc_call(lib, eng, syn, dst) == 0, lib.hevcrecon_last_error(eng.ctx)
+        got = eng.download(dst)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), (name, pic.poc, c)
+        assert eng.md5([dst]) == [pic.stage_md5[2]]
+        syn.close()
+        eng.close()
+
+
 def _synthetic_dc_picture(sp):
     """A picture made up here, not decoded: every CTU split into 32x32 intra coding units predicted with the DC mode,
     no residual, SAO off.  With no neighbours available anywhere before the first block, every sample comes out as
@@ -258,3 +290,9 @@ def test_emulated_known_answer_dc_picture(emu_lib):
     eng, syn = _known_answer_dc_picture(emu_lib, 136, 72, 10)  # sizes that are not multiples of the CTU
     syn.close()
     eng.close()
+
+
+def test_emulated_noalloc_entry_point(emu_lib):
+    """hevcrecon_reconstruct_noalloc on the emulator: two calls in a row on the one fixed work area (an I picture, then
+    a B picture with fewer blocks), each against hevcrecon_reconstruct."""
+    _noalloc_matches_regular(emu_lib, ("cip_416x240", 0), ("cip_416x240", 2))
