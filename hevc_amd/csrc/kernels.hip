@@ -58,6 +58,14 @@ __device__ __forceinline__ unsigned hr_brev(unsigned v) { return __brev(v); }
 template <typename pel_t>
 __device__ __forceinline__ const pel_t *plane_c(const void *p) { return (const pel_t *)p; }
 
+// Pointers that a kernel loads from memory (picture planes out of the job descriptor) are generic to the compiler,
+// and generic accesses are slower to issue and to wait for than global ones: hot loops say what they are.
+#ifdef HEVCRECON_EMULATE
+#define HR_GLOBAL
+#else
+#define HR_GLOBAL __attribute__((address_space(1)))
+#endif
+
 // Hand-over of data between workgroups of ONE launch (the intra kernel's CTUs).  The L1 of a compute unit is never
 // refreshed by another unit's stores and plain stores may sit in the L2 of their chiplet, so:
 //   producer  write-through stores (hr_store_through) -> every storing wave waits for its stores (hr_drain_stores)
@@ -587,13 +595,25 @@ __device__ __forceinline__ unsigned pack16(int lo, int hi) { return __builtin_am
 struct __attribute__((packed)) HrBytes16 {
   unsigned v[4];
 };
+// 16 bytes from any address of a picture plane (one unaligned global_load_dwordx4)
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ void hr_load16(const void *p, unsigned w[4]) {
+  const HrBytes16 q = *(const HrBytes16 *)p;
+  for (int k = 0; k < 4; k++) w[k] = q.v[k];
+}
+#else
+typedef unsigned hr_u32x4 __attribute__((ext_vector_type(4)));
+typedef hr_u32x4 hr_u32x4_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ void hr_load16(const HR_GLOBAL void *p, unsigned w[4]) {
+  const hr_u32x4 q = *(const HR_GLOBAL hr_u32x4_unaligned *)p;
+  w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+}
+#endif
 
 // 16 bytes of a picture row starting at sample x0; without `fast` every sample position is clamped into the row
-__device__ __forceinline__ void tile_row_load(const uint8_t *row, int x0, int pw, bool fast, unsigned w[4]) {
+__device__ __forceinline__ void tile_row_load(const HR_GLOBAL uint8_t *row, int x0, int pw, bool fast, unsigned w[4]) {
   if (fast) {
-    const HrBytes16 q = *(const HrBytes16 *)(row + x0);
-#pragma unroll
-    for (int k = 0; k < 4; k++) w[k] = q.v[k];
+    hr_load16(row + x0, w);
   } else {
     // (the volatile no-op pins the clamping arithmetic of this rare path inside the branch; left to itself the
     // compiler computes all 16 clamped positions ahead of the branch, for every lane of every item)
@@ -609,11 +629,10 @@ __device__ __forceinline__ void tile_row_load(const uint8_t *row, int x0, int pw
 }
 
 // 16 samples (two 16-byte loads) of a row of a 16-bit picture, two samples per dword
-__device__ __forceinline__ void tile_row_load(const uint16_t *row, int x0, int pw, bool fast, unsigned w[8]) {
+__device__ __forceinline__ void tile_row_load(const HR_GLOBAL uint16_t *row, int x0, int pw, bool fast, unsigned w[8]) {
   if (fast) {
-    const HrBytes16 q0 = *(const HrBytes16 *)(row + x0), q1 = *(const HrBytes16 *)(row + x0 + 8);
-#pragma unroll
-    for (int k = 0; k < 4; k++) w[k] = q0.v[k], w[4 + k] = q1.v[k];
+    hr_load16(row + x0, w);
+    hr_load16(row + x0 + 8, w + 4);
   } else {
     int xb = x0;
 #ifndef HEVCRECON_EMULATE
@@ -646,6 +665,26 @@ __constant__ unsigned kChromaTab[8][8] = {HR_C4(0, 64, 0, 0),    HR_C4(-2, 58, 1
 __device__ __forceinline__ int hr_sdot4z(unsigned a, unsigned b) { return hr_sdot4(a, b, 0); }
 __device__ __forceinline__ int hr_sdot2z(unsigned a, unsigned b) { return hr_sdot2(a, b, 0); }
 
+// A region's description is the same for every lane of its workgroup: held in scalar registers, so that everything
+// derived from it (tap tables, reference planes, which paths run) is scalar work and scalar branches as well.
+struct McTileU {
+  int x, y, mvx[2], mvy[2], ref[2];
+};
+__device__ __forceinline__ McTileU load_tile_uniform(const McTile *p) {
+  const uint4 q = *(const uint4 *)p;  // 16 bytes: x, y | mv[0] | mv[1] | ref[0], ref[1], pad
+  const unsigned w0 = hr_uniform(q.x), w1 = hr_uniform(q.y), w2 = hr_uniform(q.z), w3 = hr_uniform(q.w);
+  McTileU t;
+  t.x = (int)(w0 & 0xffffu);
+  t.y = (int)(w0 >> 16);
+  t.mvx[0] = (int)(int16_t)(w1 & 0xffffu);
+  t.mvy[0] = (int)(int16_t)(w1 >> 16);
+  t.mvx[1] = (int)(int16_t)(w2 & 0xffffu);
+  t.mvy[1] = (int)(int16_t)(w2 >> 16);
+  t.ref[0] = (int)(int8_t)(w3 & 0xffu);
+  t.ref[1] = (int)(int8_t)((w3 >> 8) & 0xffu);
+  return t;
+}
+
 template <typename pel_t, int TS, int NTHR, bool WP>
 __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_tile(const PicJob *jobs, SeqInfo s) {
   constexpr bool W16 = sizeof(pel_t) == 2;  // 16-bit planes: 16-bit dot products in the horizontal pass too
@@ -666,12 +705,12 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
   const int n = J.n_mc_tile[LVL], per_xcd = (n + 7) >> 3;
   const int idx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if ((int)(blockIdx.x >> 3) >= per_xcd || idx >= n) return;
-  const McTile t = J.mc_tile[LVL][idx];
+  const McTileU t = load_tile_uniform(&J.mc_tile[LVL][idx]);
   const int tid = threadIdx.x;
   const int rx = t.x, ry = t.y;
   // a list with a zero vertical fraction needs no vertical filter: its rows outside the block are never read
-  const bool vid_y[2] = {(t.mv[0][1] & 3) == 0, (t.mv[1][1] & 3) == 0};
-  const bool vid_c[2] = {(t.mv[0][1] & 7) == 0, (t.mv[1][1] & 7) == 0};
+  const bool vid_y[2] = {(t.mvy[0] & 3) == 0, (t.mvy[1] & 3) == 0};
+  const bool vid_c[2] = {(t.mvy[0] & 7) == 0, (t.mvy[1] & 7) == 0};
 
   // ---- phase H ----
   // item -> (luma/chroma, component, row pair p, output group o) of list l
@@ -687,7 +726,7 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
 #pragma unroll
   for (int l = 0; l < 2; l++) {
     const int ri = t.ref[l] >= 0 ? t.ref[l] : 0;
-    const int mvx = t.mv[l][0], mvy = t.mv[l][1];
+    const int mvx = t.mvx[l], mvy = t.mvy[l];
     const int wx0 = rx + (mvx >> 2) - 3, wy0 = ry + (mvy >> 2) - 3;
     const int cwx0 = (rx >> 1) + (mvx >> 3) - 1, cwy0 = (ry >> 1) + (mvy >> 3) - 1;
     const bool fast_y = wx0 >= 0 && wx0 + TS + 6 < s.w, fast_c = cwx0 >= 0 && cwx0 + CS + 2 < s.cw;
@@ -695,7 +734,7 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
     for (int it = 0; it < HIT; it++) {
       MT_DECODE
       if (live) {
-        const pel_t *base = (const pel_t *)(chroma ? (comp ? J.ref[l][ri][2] : J.ref[l][ri][1]) : J.ref[l][ri][0]);
+        const HR_GLOBAL pel_t *base = (const HR_GLOBAL pel_t *)(chroma ? (comp ? J.ref[l][ri][2] : J.ref[l][ri][1]) : J.ref[l][ri][0]);
         const int stride = chroma ? s.stride_c : s.stride_y, pw = chroma ? s.cw : s.w, ph = chroma ? s.ch : s.h;
         const int x0 = (chroma ? cwx0 : wx0) + 8 * o, y0 = chroma ? cwy0 : wy0;
         const int last = chroma ? CS + 2 : TS + 6;
@@ -710,7 +749,7 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
   }
 #pragma unroll
   for (int l = 0; l < 2; l++) {
-    const unsigned *lt = kLumaTab[t.mv[l][0] & 3], *ct = kChromaTab[t.mv[l][0] & 7];
+    const unsigned *lt = kLumaTab[t.mvx[l] & 3], *ct = kChromaTab[t.mvx[l] & 7];
     const unsigned c_lo = lt[0], c_hi = lt[1], c4 = ct[0];
 #pragma unroll
     for (int it = 0; it < HIT; it++) {
@@ -740,6 +779,21 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
                                         : hr_sdot2(x[d + 1], ct[2], hr_sdot2(x[d], ct[1], init));
                 h[rr][i] = sum >> s1;
               }
+            }
+          }
+        } else if ((chroma ? t.mvx[l] & 7 : t.mvx[l] & 3) == 0) {
+          // whole-sample horizontal position (TComInterpolationFilter::filterCopy, or the identity tap): the
+          // intermediate is the sample itself, 64 * (p - 128); output i is window byte i + 3 (luma) / i + 1 (chroma)
+#pragma unroll
+          for (int rr = 0; rr < 2; rr++) {
+            unsigned x[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = w[l][it][rr][i] ^ 0x80808080u;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+              const int jl = i + 3, jc = i + 1;
+              const int vl = (int)(int8_t)(x[jl >> 2] >> (8 * (jl & 3))), vc = (int)(int8_t)(x[jc >> 2] >> (8 * (jc & 3)));
+              h[rr][i] = (chroma ? vc : vl) * 64;
             }
           }
         } else if (!chroma) {
@@ -801,7 +855,7 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
             acc[1][c] += WP ? __mul24(Ry.w[l], a1) : a1;
           }
         } else {
-          const unsigned *lt = kLumaTab[t.mv[l][1] & 3];
+          const unsigned *lt = kLumaTab[t.mvy[l] & 3];
           const unsigned e0 = lt[2], e1 = lt[3], e2 = lt[4], e3 = lt[5], o0 = lt[6], o1 = lt[7], o2 = lt[8], o3 = lt[9], o4 = lt[10];
           unsigned qq[5][4];
 #pragma unroll
@@ -827,11 +881,11 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
             int px[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) px[c] = tile_px(acc[j][c], Ry.add, Ry.sh, max_y, WP ? Ry.post : 0);
-            pel_t *o = (pel_t *)J.rec[0] + (size_t)y * s.stride_y + rx + 4 * q;
+            HR_GLOBAL pel_t *o = (HR_GLOBAL pel_t *)J.rec[0] + (size_t)y * s.stride_y + rx + 4 * q;
             if constexpr (W16)
-              *(uint2 *)o = make_uint2(pack16(px[0], px[1]), pack16(px[2], px[3]));
+              *(HR_GLOBAL unsigned long long *)o = (unsigned long long)pack16(px[0], px[1]) | ((unsigned long long)pack16(px[2], px[3]) << 32);
             else
-              *(unsigned *)o = pack4(px[0], px[1], px[2], px[3]);
+              *(HR_GLOBAL unsigned *)o = pack4(px[0], px[1], px[2], px[3]);
           }
         }
       }
@@ -855,7 +909,7 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
             acc[1][c] += WP ? __mul24(Rc.w[l], a1) : a1;
           }
         } else {
-          const unsigned *ct = kChromaTab[t.mv[l][1] & 7];
+          const unsigned *ct = kChromaTab[t.mvy[l] & 7];
           const unsigned e0 = ct[1], e1 = ct[2], o0 = ct[3], o1 = ct[4], o2 = ct[5];
           unsigned qq[3][4];
 #pragma unroll
@@ -881,11 +935,11 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
             int px[4];
 #pragma unroll
             for (int c = 0; c < 4; c++) px[c] = tile_px(acc[j][c], Rc.add, Rc.sh, max_c, WP ? Rc.post : 0);
-            pel_t *o = (pel_t *)J.rec[1 + comp] + (size_t)y * s.stride_c + cx;
+            HR_GLOBAL pel_t *o = (HR_GLOBAL pel_t *)J.rec[1 + comp] + (size_t)y * s.stride_c + cx;
             if constexpr (W16)
-              *(uint2 *)o = make_uint2(pack16(px[0], px[1]), pack16(px[2], px[3]));
+              *(HR_GLOBAL unsigned long long *)o = (unsigned long long)pack16(px[0], px[1]) | ((unsigned long long)pack16(px[2], px[3]) << 32);
             else
-              *(unsigned *)o = pack4(px[0], px[1], px[2], px[3]);
+              *(HR_GLOBAL unsigned *)o = pack4(px[0], px[1], px[2], px[3]);
           }
         }
       }
