@@ -271,10 +271,36 @@ struct __attribute__((packed)) HrBytes12 {
 struct __attribute__((packed)) HrBytes8 {
   unsigned v[2];
 };
+// 12 / 8 bytes from any address of a picture plane (one unaligned global load)
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ void hr_load12(const void *p, unsigned w[3]) {
+  const HrBytes12 q = *(const HrBytes12 *)p;
+  for (int k = 0; k < 3; k++) w[k] = q.v[k];
+}
+__device__ __forceinline__ void hr_load8(const void *p, unsigned w[2]) {
+  const HrBytes8 q = *(const HrBytes8 *)p;
+  for (int k = 0; k < 2; k++) w[k] = q.v[k];
+}
+#else
+typedef unsigned hr_u32x4 __attribute__((ext_vector_type(4)));
+typedef hr_u32x4 hr_u32x4_unaligned __attribute__((aligned(1)));
+typedef unsigned hr_u32x3 __attribute__((ext_vector_type(3)));
+typedef hr_u32x3 hr_u32x3_unaligned __attribute__((aligned(1)));
+typedef unsigned hr_u32x2 __attribute__((ext_vector_type(2)));
+typedef hr_u32x2 hr_u32x2_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ void hr_load12(const HR_GLOBAL void *p, unsigned w[3]) {
+  const hr_u32x3 q = *(const HR_GLOBAL hr_u32x3_unaligned *)p;
+  w[0] = q.x, w[1] = q.y, w[2] = q.z;
+}
+__device__ __forceinline__ void hr_load8(const HR_GLOBAL void *p, unsigned w[2]) {
+  const hr_u32x2 q = *(const HR_GLOBAL hr_u32x2_unaligned *)p;
+  w[0] = q.x, w[1] = q.y;
+}
+#endif
 
 // Window of a BW x BH block for an NT-tap filter: ROWS rows of NW dwords, samples biased by 128.
 template <int NT, int BW, int BH>
-__device__ __forceinline__ void interp_u8_load(const uint8_t *ref, int stride, int pw, int ph, int x0, int y0, bool v_identity,
+__device__ __forceinline__ void interp_u8_load(const HR_GLOBAL uint8_t *ref, int stride, int pw, int ph, int x0, int y0, bool v_identity,
                                                unsigned w[BH + NT - 1][(BW + NT - 1 + 3) / 4]) {
   constexpr int HALF = NT / 2 - 1;
   constexpr int NPIX = BW + NT - 1;
@@ -288,15 +314,15 @@ __device__ __forceinline__ void interp_u8_load(const uint8_t *ref, int stride, i
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
       const int rr = v_identity ? clip3i(HALF, HALF + BH - 1, r) : r;
-      const uint8_t *rp = ref + (size_t)(ys + rr) * stride + xs;  // unaligned loads
+      const HR_GLOBAL uint8_t *rp = ref + (size_t)(ys + rr) * stride + xs;  // unaligned loads
       if constexpr (NW == 3) {
-        const HrBytes12 q = *(const HrBytes12 *)rp;
+        hr_load12(rp, w[r]);
 #pragma unroll
-        for (int k = 0; k < 3; k++) w[r][k] = q.v[k] ^ 0x80808080u;
+        for (int k = 0; k < 3; k++) w[r][k] ^= 0x80808080u;
       } else {
-        const HrBytes8 q = *(const HrBytes8 *)rp;
+        hr_load8(rp, w[r]);
 #pragma unroll
-        for (int k = 0; k < 2; k++) w[r][k] = q.v[k] ^ 0x80808080u;
+        for (int k = 0; k < 2; k++) w[r][k] ^= 0x80808080u;
       }
     }
   } else {
@@ -306,7 +332,7 @@ __device__ __forceinline__ void interp_u8_load(const uint8_t *ref, int stride, i
 #endif
 #pragma unroll
     for (int r = 0; r < ROWS; r++) {
-      const uint8_t *row = ref + (size_t)clip3i(0, ph - 1, ys + r) * stride;
+      const HR_GLOBAL uint8_t *row = ref + (size_t)clip3i(0, ph - 1, ys + r) * stride;
 #pragma unroll
       for (int k = 0; k < NW; k++) w[r][k] = 0;
 #pragma unroll
@@ -437,11 +463,11 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
       const int ri = p.ref_idx[l];
       mvx[l] = min(hmax, max(hmin, (int)p.mv[l][0]));
       mvy[l] = min(vmax, max(vmin, (int)p.mv[l][1]));
-      interp_u8_load<8, 4, 4>((const uint8_t *)J.ref[l][ri][0], s.stride_y, s.w, s.h, x + (mvx[l] >> 2), y + (mvy[l] >> 2),
+      interp_u8_load<8, 4, 4>((const HR_GLOBAL uint8_t *)J.ref[l][ri][0], s.stride_y, s.w, s.h, x + (mvx[l] >> 2), y + (mvy[l] >> 2),
                               (mvy[l] & 3) == 0, wy[l]);
 #pragma unroll
       for (int c = 0; c < 2; c++)
-        interp_u8_load<4, 2, 2>((const uint8_t *)J.ref[l][ri][1 + c], s.stride_c, s.cw, s.ch, (x >> 1) + (mvx[l] >> 3),
+        interp_u8_load<4, 2, 2>((const HR_GLOBAL uint8_t *)J.ref[l][ri][1 + c], s.stride_c, s.cw, s.ch, (x >> 1) + (mvx[l] >> 3),
                                 (y >> 1) + (mvy[l] >> 3), (mvy[l] & 7) == 0, wc[l][c]);
     }
 #pragma unroll
@@ -601,12 +627,20 @@ __device__ __forceinline__ void hr_load16(const void *p, unsigned w[4]) {
   const HrBytes16 q = *(const HrBytes16 *)p;
   for (int k = 0; k < 4; k++) w[k] = q.v[k];
 }
+__device__ __forceinline__ void hr_store16(void *p, unsigned a, unsigned b, unsigned c, unsigned d) {
+  unsigned *q = (unsigned *)p;
+  q[0] = a, q[1] = b, q[2] = c, q[3] = d;
+}
 #else
-typedef unsigned hr_u32x4 __attribute__((ext_vector_type(4)));
-typedef hr_u32x4 hr_u32x4_unaligned __attribute__((aligned(1)));
 __device__ __forceinline__ void hr_load16(const HR_GLOBAL void *p, unsigned w[4]) {
   const hr_u32x4 q = *(const HR_GLOBAL hr_u32x4_unaligned *)p;
   w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+}
+// 16 bytes to a 16-byte aligned address
+__device__ __forceinline__ void hr_store16(HR_GLOBAL void *p, unsigned a, unsigned b, unsigned c, unsigned d) {
+  hr_u32x4 q;
+  q.x = a, q.y = b, q.z = c, q.w = d;
+  *(HR_GLOBAL hr_u32x4 *)p = q;
 }
 #endif
 
@@ -1598,6 +1632,17 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
 // ------------------------------------------------------------------------------------------------
 // k_deblock: one lane per 4-sample edge segment
 // ------------------------------------------------------------------------------------------------
+// a 16-byte motion record through a global pointer
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ Part4 hr_load_part4(const Part4 *p) { return *p; }
+#else
+__device__ __forceinline__ Part4 hr_load_part4(const HR_GLOBAL Part4 *p) {
+  const hr_u32x4 q = *(const HR_GLOBAL hr_u32x4 *)p;
+  Part4 r;
+  __builtin_memcpy(&r, &q, sizeof(r));
+  return r;
+}
+#endif
 __device__ __forceinline__ int tu_size_of(const Part4 &p) { return (64 >> (p.flags & P4_DEPTH_MASK)) >> (p.tu & P4_TRIDX_MASK); }
 
 // TComLoopFilter::xGetBoundaryStrengthSingle (TLibCommon/TComLoopFilter.cpp:421-543)
@@ -1644,8 +1689,9 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
   if (e == 0 || e >= n_edge || u >= n_unit) return;
   const int x = DIR == 0 ? e * 8 : u * 4, y = DIR == 0 ? u * 4 : e * 8;
   const int ux = x >> 2, uy = y >> 2;
-  const Part4 Q = J.rec4[(size_t)uy * s.uw + ux];
-  const Part4 P = DIR == 0 ? J.rec4[(size_t)uy * s.uw + ux - 1] : J.rec4[(size_t)(uy - 1) * s.uw + ux];
+  const HR_GLOBAL Part4 *r4 = (const HR_GLOBAL Part4 *)J.rec4;
+  const Part4 Q = hr_load_part4(r4 + (size_t)uy * s.uw + ux);
+  const Part4 P = hr_load_part4(DIR == 0 ? r4 + (size_t)uy * s.uw + ux - 1 : r4 + (size_t)(uy - 1) * s.uw + ux);
   const int pos = DIR == 0 ? x : y;
   const bool tu_edge = (pos & (tu_size_of(Q) - 1)) == 0;
   if (!tu_edge) {
@@ -1676,21 +1722,21 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
     const int tc = kTc[clip3i(0, 53, qp + 2 * (bs - 1) + 2 * J.tc_off_div2)] * scale;
     const int beta = kBeta[clip3i(0, 51, qp + 2 * J.beta_off_div2)] * scale;
     const int step = DIR == 0 ? 1 : s.stride_y, line = DIR == 0 ? s.stride_y : 1;
-    pel_t *sp = (pel_t *)J.rec[0] + (size_t)y * s.stride_y + x;
+    HR_GLOBAL pel_t *sp = (HR_GLOBAL pel_t *)J.rec[0] + (size_t)y * s.stride_y + x;
     int m[4][8];  // m[k][0..3] = p3..p0, m[k][4..7] = q0..q3 of line k
     if constexpr (sizeof(pel_t) == 1) {
       // byte planes: the 4x8 (8x4) samples around the segment as aligned dwords (x is a multiple of 4)
       if (DIR == 0) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const unsigned lo = *(const unsigned *)(sp + k * line - 4), hi = *(const unsigned *)(sp + k * line);
+          const unsigned lo = *(const HR_GLOBAL unsigned *)(sp + k * line - 4), hi = *(const HR_GLOBAL unsigned *)(sp + k * line);
 #pragma unroll
           for (int i = 0; i < 4; i++) m[k][i] = (lo >> (8 * i)) & 255, m[k][4 + i] = (hi >> (8 * i)) & 255;
         }
       } else {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-          const unsigned w = *(const unsigned *)(sp + (i - 4) * step);
+          const unsigned w = *(const HR_GLOBAL unsigned *)(sp + (i - 4) * step);
 #pragma unroll
           for (int k = 0; k < 4; k++) m[k][i] = (w >> (8 * k)) & 255;
         }
@@ -1752,12 +1798,12 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
         if (DIR == 0) {
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            *(unsigned *)(sp + k * line - 4) = pack4(r[k][0], r[k][1], r[k][2], r[k][3]);
-            *(unsigned *)(sp + k * line) = pack4(r[k][4], r[k][5], r[k][6], r[k][7]);
+            *(HR_GLOBAL unsigned *)(sp + k * line - 4) = pack4(r[k][0], r[k][1], r[k][2], r[k][3]);
+            *(HR_GLOBAL unsigned *)(sp + k * line) = pack4(r[k][4], r[k][5], r[k][6], r[k][7]);
           }
         } else {
 #pragma unroll
-          for (int i = 1; i < 7; i++) *(unsigned *)(sp + (i - 4) * step) = pack4(r[0][i], r[1][i], r[2][i], r[3][i]);
+          for (int i = 1; i < 7; i++) *(HR_GLOBAL unsigned *)(sp + (i - 4) * step) = pack4(r[0][i], r[1][i], r[2][i], r[3][i]);
         }
       } else {
 #pragma unroll
@@ -1777,10 +1823,10 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
       int qc = qp + (c == 0 ? J.cb_off_pps : J.cr_off_pps);
       qc = qc < 0 ? qc : (qc > 57 ? qc - 6 : kChromaScale[qc]);
       const int tc = kTc[clip3i(0, 53, qc + 2 + 2 * J.tc_off_div2)] * scale;
-      pel_t *sp = (pel_t *)J.rec[1 + c] + (size_t)(y >> 1) * s.stride_c + (x >> 1);
+      HR_GLOBAL pel_t *sp = (HR_GLOBAL pel_t *)J.rec[1 + c] + (size_t)(y >> 1) * s.stride_c + (x >> 1);
 #pragma unroll
       for (int k = 0; k < 2; k++) {
-        pel_t *o = sp + k * line;
+        HR_GLOBAL pel_t *o = sp + k * line;
         const int m2 = o[-2 * step], m3 = o[-step], m4 = o[0], m5 = o[step];
         const int delta = clip3i(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
         if (!keep_p) o[-step] = (pel_t)clip3i(0, maxv, m3 + delta);
@@ -1807,8 +1853,8 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
   const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
   const int x = (blockIdx.x * 64 + threadIdx.x) * 16, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= pw || y >= ph) return;
-  const pel_t *src = (const pel_t *)J.rec[comp];
-  pel_t *dst = (pel_t *)J.out[comp];
+  const HR_GLOBAL pel_t *src = (const HR_GLOBAL pel_t *)J.rec[comp];
+  HR_GLOBAL pel_t *dst = (HR_GLOBAL pel_t *)J.out[comp];
   const int csh = comp ? 5 : 6;
   const SaoCtu sp = J.sao[((size_t)(y >> csh) * s.ctus_w + (x >> csh)) * 3 + comp];
   const bool on = (comp ? J.sao_chroma : J.sao_luma) && sp.type >= 0;
@@ -1829,20 +1875,17 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
     table = (unsigned long long)(uint8_t)sp.offset[0] | ((unsigned long long)(uint8_t)sp.offset[1] << 8) |
             ((unsigned long long)(uint8_t)sp.offset[2] << 16) | ((unsigned long long)(uint8_t)sp.offset[3] << 24);
   const int dyr = dy && rows_ok ? stride : 0;
-  const pel_t *row = src + (size_t)y * stride;
+  const HR_GLOBAL pel_t *row = src + (size_t)y * stride;
   // A row's samples x-4/B .. x+16+4/B-1 as packed dwords (B = bytes per sample): one dword left of the lane's 16
   // samples, the samples, one dword right.  Reads past the picture width stay inside the padded row (or the slack
   // after the last plane) and are never used: such neighbours make the sample a border sample.
   constexpr int SPD = 4 / sizeof(pel_t);   // samples per dword
   constexpr int ND = 16 / SPD;             // dwords holding the lane's 16 samples
-  auto fetch = [&](const pel_t *rp, unsigned w[ND + 2]) {
-    w[0] = x > 0 ? *(const unsigned *)(rp + x - SPD) : 0u;
+  auto fetch = [&](const HR_GLOBAL pel_t *rp, unsigned w[ND + 2]) {
+    w[0] = x > 0 ? *(const HR_GLOBAL unsigned *)(rp + x - SPD) : 0u;
 #pragma unroll
-    for (int k = 0; k < ND / 4; k++) {
-      const uint4 m = *(const uint4 *)(rp + x + 4 * SPD * k);
-      w[1 + 4 * k] = m.x, w[2 + 4 * k] = m.y, w[3 + 4 * k] = m.z, w[4 + 4 * k] = m.w;
-    }
-    w[ND + 1] = *(const unsigned *)(rp + x + 16);
+    for (int k = 0; k < ND / 4; k++) hr_load16(rp + x + 4 * SPD * k, w + 1 + 4 * k);
+    w[ND + 1] = *(const HR_GLOBAL unsigned *)(rp + x + 16);
   };
   // the 16 samples starting `shift` samples (-1, 0, 1) from the lane's first one, still packed
   auto shifted = [&](const unsigned w[ND + 2], int shift, unsigned o[ND]) {
@@ -1893,27 +1936,20 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
       if (ux < s.uw && (J.rec4[(size_t)uy * s.uw + ux].flags & P4_BYPASS)) v[i] = sample(pc, i);
     }
   }
-  pel_t *orow = dst + (size_t)y * stride + x;
+  HR_GLOBAL pel_t *orow = dst + (size_t)y * stride + x;
   if constexpr (sizeof(pel_t) == 1) {
     if (x + 16 <= pw) {
-      uint4 o4;
-      o4.x = pack4(v[0], v[1], v[2], v[3]);
-      o4.y = pack4(v[4], v[5], v[6], v[7]);
-      o4.z = pack4(v[8], v[9], v[10], v[11]);
-      o4.w = pack4(v[12], v[13], v[14], v[15]);
-      *(uint4 *)orow = o4;
+      hr_store16(orow, pack4(v[0], v[1], v[2], v[3]), pack4(v[4], v[5], v[6], v[7]), pack4(v[8], v[9], v[10], v[11]),
+                 pack4(v[12], v[13], v[14], v[15]));
     } else {
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        if (x + 4 * q < pw) *(unsigned *)(orow + 4 * q) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        if (x + 4 * q < pw) *(HR_GLOBAL unsigned *)(orow + 4 * q) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
   } else {
     if (x + 16 <= pw) {
-      uint4 o0, o1;
-      o0.x = pack16(v[0], v[1]), o0.y = pack16(v[2], v[3]), o0.z = pack16(v[4], v[5]), o0.w = pack16(v[6], v[7]);
-      o1.x = pack16(v[8], v[9]), o1.y = pack16(v[10], v[11]), o1.z = pack16(v[12], v[13]), o1.w = pack16(v[14], v[15]);
-      ((uint4 *)orow)[0] = o0;
-      ((uint4 *)orow)[1] = o1;
+      hr_store16(orow, pack16(v[0], v[1]), pack16(v[2], v[3]), pack16(v[4], v[5]), pack16(v[6], v[7]));
+      hr_store16(orow + 8, pack16(v[8], v[9]), pack16(v[10], v[11]), pack16(v[12], v[13]), pack16(v[14], v[15]));
     } else {
 #pragma unroll
       for (int i = 0; i < 16; i++)
