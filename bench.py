@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """Benchmark of the picture-reconstruction engine on MI355X.
 
-Workload: the 1920x1080, 60-frame random-access stream encoded by the reference
-encoder (cfg/encoder_randomaccess_main.cfg) from the synthetic clip of tools/gen_clip.py, as parsed by the
-reference decoder (tests/golden/randomaccess_main_1920x1080.syn.xz).  Each GPU reconstructs `--streams`
-independent copies of that stream (the stream-sharded multi-stream case), pictures of equal decoding
-position batched into one set of launches.  A step = one pass over all 60 pictures of every stream.
-The packed syntax is resident in HBM before the timed region starts; every final picture is MD5-checked
-against the reference decoder's digest after it.
+Workload: 1920x1080, 60-frame random-access streams encoded by the reference encoder
+(cfg/encoder_randomaccess_main.cfg) from the synthetic clips of tools/gen_clip.py, eight different clips (seeds
+20240607 .. 20240614), as parsed by the reference decoder (tests/golden/randomaccess_main_1920x1080*.syn.xz).
+Each GPU reconstructs `--streams` independent streams (the stream-sharded multi-stream case): stream s plays clip
+s mod 8, over and over, in decoding order.  The streams of a GPU are spread over `--contexts` engine contexts; a
+context batches the pictures its streams have reached into one set of launches per step.  Streams of one context
+run at the same decoding position (a host that batches groups streams by position, so that the long dependency
+chain of intra pictures is shared by a whole batch); the contexts are half a stream apart.  `--stagger` instead
+starts every stream at its own position.
+
+A step = every stream advances by 60 pictures.  The packed syntax is resident in HBM before the timed region
+starts; after it, one more pass checks every final picture of every stream against the reference decoder's MD5.
 
 Prints one JSON line (rank 0).
 """
@@ -26,6 +31,8 @@ from hevc_amd import engine, sharding, syntax  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak
 ID_STRIDE = 128         # picture ids of stream s are offset by s * ID_STRIDE
+KERNELS = ["k_inter_tile64", "k_inter_tile32", "k_inter_tile16", "k_inter_blk", "k_transform", "k_intra", "k_deblock_v",
+           "k_deblock_h", "k_sao"]
 
 
 def clone_for_stream(pic, s):
@@ -37,49 +44,71 @@ def clone_for_stream(pic, s):
     return p
 
 
-def kernel_bytes(seq, stats_list, sao_flags):
-    """Algorithmic bytes per kernel for a list of pictures: the terms of
+def kernel_bytes(sp, st, sao):
+    """Algorithmic bytes per kernel for one picture (its packing statistics `st`): the terms of
     S*b*(1 store + 2 deblock + 2 SAO) + MC reference reads + 2*coefficients + 16 per 4x4 record (or 16 per
     uniform-motion region), attributed to the kernel that moves them.  Luma + chroma = 1.5 bytes per luma
     sample at 8 bits."""
-    sp = seq.seq_params
     b = 2 if sp.bit_depth_luma > 8 else 1
     s_bytes = sp.width * sp.height * 3 // 2 * b
-    names = ["k_inter_tile64", "k_inter_tile32", "k_inter_tile16", "k_inter_blk", "k_transform", "k_intra", "k_deblock_v",
-             "k_deblock_h", "k_sao"]
-    out = dict.fromkeys(names, 0)
-    for st, sao in zip(stats_list, sao_flags):
-        n4, intra4 = st[8], st[9]
-        tile_samples = tile_ref_samples = 0
-        for t, name in enumerate(names[:3]):
-            out[name] += (st[23 + t] + st[26 + t]) * 3 // 2 * b + 16 * st[16 + t]
-            tile_samples += st[23 + t]
-            tile_ref_samples += st[26 + t]
-        blk_units = (n4 - intra4) - tile_samples // 16
-        out["k_inter_blk"] += blk_units * 24 * b + (st[7] - tile_ref_samples * 3 // 2) * b + 16 * blk_units
-        out["k_intra"] += intra4 * 24 * b
-        out["k_transform"] += 2 * st[4]
-        out["k_deblock_v"] += s_bytes
-        out["k_deblock_h"] += s_bytes
-        out["k_sao"] += 2 * s_bytes if sao else 0
+    out = dict.fromkeys(KERNELS, 0)
+    n4, intra4 = st[8], st[9]
+    tile_samples = tile_ref_samples = 0
+    for t, name in enumerate(KERNELS[:3]):
+        out[name] += (st[23 + t] + st[26 + t]) * 3 // 2 * b + 16 * st[16 + t]
+        tile_samples += st[23 + t]
+        tile_ref_samples += st[26 + t]
+    blk_units = (n4 - intra4) - tile_samples // 16
+    out["k_inter_blk"] += blk_units * 24 * b + (st[7] - tile_ref_samples * 3 // 2) * b + 16 * blk_units
+    out["k_intra"] += intra4 * 24 * b
+    out["k_transform"] += 2 * st[4]
+    out["k_deblock_v"] += s_bytes
+    out["k_deblock_h"] += s_bytes
+    out["k_sao"] += 2 * s_bytes if sao else 0
     return out
 
 
-def cpu_baseline(seconds_target=12.0):
-    """Reference decoder (HM 9.1 TAppDecoder, -O3, one thread) on the same bitstream, host cores of this machine."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "TAppDecoder")
-    bits = os.path.join(ROOT, "tests", "golden", "randomaccess_main_1080.bin")
-    if os.path.exists(exe) and os.access(exe, os.X_OK) and os.path.exists(bits):
+REF_DECODER = os.path.join(ROOT, "oracle", "_ref", "TAppDecoder")
+BRIDGE_DECODER = os.path.join(ROOT, "oracle", "_ref", "TAppDecoderBridge")
+RA_BITSTREAM = os.path.join(ROOT, "tests", "golden", "randomaccess_main_1080.bin")
+
+
+def _decode_once(exe, env=None):
+    t0 = time.time()
+    out = subprocess.run([exe, "-b", RA_BITSTREAM], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True, env=env).stdout.decode("latin1")
+    if out.count("(OK)") != 60:
+        raise RuntimeError("%s did not report 60 matching pictures" % os.path.basename(exe))
+    return time.time() - t0
+
+
+def cpu_baseline(seconds_target=10.0):
+    """Reference decoder (HM 9.1 TAppDecoder, -O3, single-threaded; parse + reconstruction + MD5 check) on the 1080p RA
+    bitstream, on the host cores of this machine: N concurrent decoders, one stream per core, N = the cores this job
+    may use (at most 16), and the single-process figure."""
+    if os.path.exists(REF_DECODER) and os.access(REF_DECODER, os.X_OK) and os.path.exists(RA_BITSTREAM):
         frames, t0 = 0, time.time()
-        while time.time() - t0 < seconds_target:
-            out = subprocess.run([exe, "-b", bits], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, check=True).stdout.decode("latin1")
-            n = out.count("(OK)")
-            if n != 60:
-                raise RuntimeError("reference decoder did not report 60 matching pictures")
-            frames += n
-        dt = time.time() - t0
-        return {"value": round(frames / dt, 2), "unit": "frames/s", "cores": 1, "kind": "reference",
-                "sample": "%d runs of the 60-frame 1080p RA stream through oracle/_ref/TAppDecoder (parse + reconstruction + MD5 check), %.1f s" % (frames // 60, dt)}
+        while time.time() - t0 < seconds_target / 2:
+            _decode_once(REF_DECODER)
+            frames += 60
+        t_single = time.time() - t0
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncores = os.cpu_count() or 1
+        n = max(1, min(16, ncores))
+        loop = ("import subprocess,sys,time\nt0=time.time();k=0\nwhile time.time()-t0<%f:\n"
+                "    o=subprocess.run([%r,'-b',%r],stdout=subprocess.PIPE,stderr=subprocess.STDOUT).stdout\n"
+                "    assert o.count(b'(OK)')==60\n    k+=60\nprint(k, time.time()-t0)\n") % (seconds_target / 2, REF_DECODER, RA_BITSTREAM)
+        t0 = time.time()
+        procs = [subprocess.Popen([sys.executable, "-c", loop], stdout=subprocess.PIPE) for _ in range(n)]
+        outs = [p.communicate()[0].split() for p in procs]
+        wall = time.time() - t0
+        total = sum(int(o[0]) for o in outs)
+        return {"value": round(total / wall, 2), "unit": "frames/s", "cores": n, "kind": "reference",
+                "single_process_value": round(frames / t_single, 2),
+                "sample": "%d concurrent single-threaded oracle/_ref/TAppDecoder processes decoding the 60-frame 1080p RA stream "
+                          "(parse + reconstruction + MD5 check) for %.1f s: %d frames; one process alone: %d frames in %.1f s"
+                          % (n, wall, total, frames, t_single)}
     # the reference binary did not travel: time the C restatement (reconstruction only) instead
     from oracle.refmodel import RefModel
 
@@ -91,6 +120,25 @@ def cpu_baseline(seconds_target=12.0):
     dt = time.time() - t0
     return {"value": round(len(seq.pictures) / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": "first %d pictures of the 1080p RA stream through oracle/recon_ref.c (reconstruction only), %.1f s" % (len(seq.pictures), dt)}
+
+
+def end_to_end(device):
+    """The reference decoder's own CLI on the 1080p RA bitstream with the engine behind it (oracle/_ref/TAppDecoderBridge,
+    HEVCRECON_MODE=engine: the reference parses, the GPU reconstructs, the reference checks every MD5) beside the
+    unmodified reference decoder, same host, wall clock of the whole process, best of two."""
+    if not (os.path.exists(BRIDGE_DECODER) and os.path.exists(REF_DECODER) and os.path.exists(RA_BITSTREAM)):
+        return None
+    from hevc_amd import abi
+
+    env = dict(os.environ, HEVCRECON_MODE="engine", HEVCRECON_LIB=abi.LIB_PATH)
+    try:
+        t_eng = min(_decode_once(BRIDGE_DECODER, env) for _ in range(2))
+        t_ref = min(_decode_once(REF_DECODER) for _ in range(2))
+    except (RuntimeError, subprocess.CalledProcessError, OSError) as e:
+        return {"error": str(e)[:200]}
+    return {"frames": 60, "engine_behind_reference_cli_frames_per_s": round(60 / t_eng, 2), "reference_cli_frames_per_s": round(60 / t_ref, 2),
+            "note": "one stream, one process, wall clock with process start and GPU initialisation; the reference's parser, its "
+                    "per-picture download and its MD5 check run on one host thread and bound the engine-backed decoder"}
 
 
 def spawn_ranks(n):
@@ -112,25 +160,101 @@ def spawn_ranks(n):
     return rc
 
 
+class Workload:
+    """The streams of one GPU: packed pictures resident in HBM, and the batches that advance every stream by one
+    picture per step.  Stream s starts at step off[s] and then plays its 60 pictures over and over (picture 0 is an
+    intra picture, so every pass is a correct decode and every picture can be checked at any time)."""
+
+    def __init__(self, seqs, S, C, device, upload_ring, stagger):
+        self.seqs, self.S, self.C = seqs, S, C
+        self.sp = seqs[0].seq_params
+        self.npic = len(seqs[0].pictures)
+        nseeds = len(seqs)
+        self.seed_of = [s % nseeds for s in range(S)]
+        self.ctx_of = [(s // nseeds) % C if S >= nseeds * C else s % C for s in range(S)]
+        self.groups = [[s for s in range(S) if self.ctx_of[s] == c] for c in range(C)]
+        self.engs = [engine.Engine(self.sp, device=device) for _ in range(C)]
+        for c in range(C):
+            self.engs[c].set_upload_ring(min(4 << 30, len(self.groups[c]) * self.npic * (256 << 10)) if upload_ring else 0)
+        # pack every picture of every stream (untimed); statistics and packing time per (clip, picture)
+        self.syns = [[None] * S for _ in range(self.npic)]
+        self.stats = [[None] * self.npic for _ in range(nseeds)]
+        self.pack_s, self.pack_n = 0.0, 0
+        for k, seq in enumerate(seqs):
+            for t, pic in enumerate(seq.pictures):
+                pic.ctu_structs()
+                for s in range(S):
+                    if self.seed_of[s] == k:
+                        y = self.engs[self.ctx_of[s]].new_syntax().pack(clone_for_stream(pic, s))
+                        self.syns[t][s] = y
+                        self.pack_s += y.pack_seconds
+                        self.pack_n += 1
+                        if self.stats[k][t] is None:
+                            self.stats[k][t] = y.stats()
+                pic.drop_ctypes()
+        self.set_offsets(stagger)
+
+    def set_offsets(self, stagger):
+        """Grouped (default): the streams of a context share their position, the contexts are 60 / C pictures apart.
+        Staggered: every stream of a context at its own position."""
+        npic = self.npic
+        self.off = [0] * self.S
+        for c, g in enumerate(self.groups):
+            for j, s in enumerate(g):
+                self.off[s] = (c * npic // self.C + (j * npic // len(g) if stagger else 0)) % npic
+        self.max_off = max(self.off)
+        self._prepared = {}
+
+    def members(self, c, g):
+        return [(s, (g - self.off[s]) % self.npic) for s in self.groups[c] if g >= self.off[s]]
+
+    def prepared(self, c, g):
+        """Argument arrays of context c's batch at step g (steps past the ramp-up repeat with period 60)."""
+        key = (c, g if g < self.max_off else self.max_off + (g - self.max_off) % self.npic)
+        if key not in self._prepared:
+            m = self.members(c, g)
+            self._prepared[key] = self.engs[c].prepare_batch([self.syns[t][s] for s, t in m], [self.pic_id(s, t) for s, t in m]) if m else None
+        return self._prepared[key]
+
+    def pic_id(self, s, t):
+        return self.seqs[self.seed_of[s]].pictures[t].pic_id + s * ID_STRIDE
+
+    def step(self, g, upload=False):
+        for c in range(self.C):
+            p = self.prepared(c, g)
+            if p is not None:
+                if upload:
+                    self.engs[c].upload_prepared(p)
+                self.engs[c].reconstruct_prepared(p)
+
+    def synchronize(self):
+        for e in self.engs:
+            e.synchronize()
+
+    def close(self):
+        for row in self.syns:
+            for y in row:
+                if y is not None:
+                    y.close()
+        for e in self.engs:
+            e.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=128,
-                    help="independent streams per GPU; larger batches amortise the latency-bound intra launches "
-                         "(measured: 64 -> 72.9 k, 128 -> 81.6 k, 256 -> 86.4 k frames/s)")
+                    help="independent streams per GPU; larger batches amortise the latency-bound intra chains")
     ap.add_argument("--contexts", type=int, default=2,
                     help="engine contexts (HIP streams) the streams of this GPU are spread over; with several, one context's "
-                         "latency-bound intra launches run beside the others' throughput-bound kernels "
-                         "(measured at 128 streams: 1 -> 81.9 k, 2 -> 88.8 k, 3 -> 91.6 k, 4 -> 92.5 k frames/s; beyond two the "
-                         "launches get so small that the latency-bound intra kernel tops the per-kernel times, and the "
-                         "hand-over of fresh pictures suffers from queue sharing)")
+                         "latency-bound intra kernel runs beside the others' throughput-bound kernels")
+    ap.add_argument("--seeds", type=int, default=8, help="different clips among the streams (the fixture and its _s1 .. _s7 variants)")
+    ap.add_argument("--stagger", action="store_true", help="every stream at its own decoding position (default: one position per context)")
     ap.add_argument("--fixture", default="randomaccess_main_1920x1080")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--merge", action="store_true",
-                    help="batch independent pictures of a stream (hierarchical-B siblings) together: 33 instead of 60 batches "
-                         "per pass of the RA stream; measured +0.4 %% with one context, -2 %% with two")
+    ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (hand-over, 1 and 8 streams, staggered, end to end)")
     ap.add_argument("--no-handover", action="store_true", help="skip the passes that time the syntax hand-over")
     ap.add_argument("--upload-ring", action="store_true", help="stage all packed pictures in the context's upload ring (coalesced hand-over copies)")
     ap.add_argument("--check-two-streams-only", action="store_true",
@@ -161,6 +285,7 @@ def main():
         if ndev:
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     if args.rehearse:
         # the N > 1 plumbing alone (spawn, rendezvous, stream sharding, barrier, reductions), for machines without a GPU
@@ -181,128 +306,93 @@ def main():
         args.streams = len(sharding.streams_for_rank(args.total_streams, rank, world))
         if args.streams == 0:
             raise SystemExit("bench: fewer streams than GPUs")
-    seq = syntax.read_dump(os.path.join(ROOT, "tests", "golden", args.fixture + ".syn.xz"))
-    sp = seq.seq_params
-    npic, S = len(seq.pictures), args.streams
+
+    golden = os.path.join(ROOT, "tests", "golden")
+    names = [args.fixture] + ["%s_s%d" % (args.fixture, k) for k in range(1, 8)]
+    names = [n for n in names if os.path.exists(os.path.join(golden, n + ".syn.xz"))][:max(1, args.seeds)]
+    seqs = [syntax.read_dump(os.path.join(golden, n + ".syn.xz")) for n in names[:max(1, min(len(names), args.streams))]]
+    sp = seqs[0].seq_params
+    S = args.streams
     C = max(1, min(args.contexts, S))
-    engs = [engine.Engine(sp, device=local_rank) for _ in range(C)]
-    eng = engs[0]
-    ctx_of = [s * C // S for s in range(S)]  # stream -> context
-    # Every packed picture stays alive here.  With --upload-ring the ring has room for all of them, so the hand-over
-    # passes copy a batch in a few pieces (measured: hand-over 53 k -> 69 k frames/s, resident rate 88.9 k -> 87.1 k
-    # with two contexts); without, every picture stages in buffers of its own.
-    for c in range(C):
-        engs[c].set_upload_ring(min(4 << 30, ctx_of.count(c) * npic * (256 << 10)) if args.upload_ring else 0)
-
-    # ---- pack every picture of every stream and make it resident in HBM (untimed) ----
-    syns = [[None] * S for _ in range(npic)]
-    stats, sao_flags = [], []
-    for t, pic in enumerate(seq.pictures):
-        pic.ctu_structs()
-        for s in range(S):
-            syns[t][s] = engs[ctx_of[s]].new_syntax().pack(clone_for_stream(pic, s))
-        stats.append(syns[t][0].stats())
-        sao_flags.append(bool(pic.pic_params.sao_luma or pic.pic_params.sao_chroma))
-        pic.drop_ctypes()
-    ids = [[pic.pic_id + s * ID_STRIDE for s in range(S)] for pic in seq.pictures]
-    alg_bytes_stream = sum(syns[t][0].algorithmic_bytes() for t in range(npic))
-    groups = [[s for s in range(S) if ctx_of[s] == c] for c in range(C)]
-    for e in engs:
-        e.synchronize()
-
-    # Batches: by default one picture position of all streams per set of launches.  With --merge, pictures of one
-    # stream that do not depend on each other (hierarchical-B siblings) share a batch: a picture's level is one more
-    # than the highest level among the pictures it reads, the previous writer of its buffer and that buffer's readers.
-    level, last_writer, readers = [], {}, {}
-    for t, pic in enumerate(seq.pictures):
-        pp = pic.pic_params
-        refs = {pp.ref_pic_id[l][r] for l in range(2) for r in range(pp.num_ref[l])}
-        lv = max([level[last_writer[r]] + 1 for r in refs] + [0])
-        if pic.pic_id in last_writer:
-            lv = max([lv, level[last_writer[pic.pic_id]] + 1] + [level[r] + 1 for r in readers[pic.pic_id]])
-        level.append(lv)
-        for r in refs:
-            readers[r].append(t)
-        last_writer[pic.pic_id], readers[pic.pic_id] = t, []
-    if not args.merge:
-        level = list(range(npic))
-    nb = max(level) + 1
-    members = [[t for t in range(npic) if level[t] == b] for b in range(nb)]
-    prepared = [[engs[c].prepare_batch([syns[t][s] for t in members[b] for s in groups[c]],
-                                       [ids[t][s] for t in members[b] for s in groups[c]]) for c in range(C)]
-                for b in range(nb)]
-
-    # Contexts run on their own HIP streams, so their kernels overlap on the GPU.  Independent streams are not in
-    # lock step in practice: context c works `phase[c]` pictures ahead (cyclically; the pictures a position refers
-    # to are resident from the previous pass), which lets one context's latency-bound intra waves run beside
-    # another's throughput-bound kernels.
-    phase = [c * nb // C for c in range(C)]
-
-    def one_step():
-        for b in range(nb):
-            for c in range(C):
-                engs[c].reconstruct_prepared(prepared[(b + phase[c]) % nb][c])
+    W = Workload(seqs, S, C, local_rank, args.upload_ring, args.stagger)
+    npic, engs, groups = W.npic, W.engs, W.groups
+    W.synchronize()
+    alg_bytes_stream = [sum(W.syns[t][s].algorithmic_bytes() for t in range(npic)) for s in range(S)]
 
     def sync():
-        for e in engs:
-            e.synchronize()
+        W.synchronize()
         if dist is not None:
             import torch
 
             torch.cuda.synchronize()
             dist.barrier()
 
-    if C > 1:  # one pass in decoding order makes every picture resident before the phase-shifted passes start
-        for b in range(nb):
-            for c in range(C):
-                engs[c].reconstruct_prepared(prepared[b][c])
-    for _ in range(args.warmup):
-        one_step()
+    def run_passes(first_step, n_pass):
+        for gg in range(first_step, first_step + n_pass * npic):
+            W.step(gg)
+        return first_step + n_pass * npic
+
+    # ramp-up (streams start one after the other) and warm-up passes, then the timed passes
+    g = 0
+    while g < W.max_off:
+        W.step(g)
+        g += 1
+    g = run_passes(g, max(1, args.warmup))
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    g = run_passes(g, args.steps)
     sync()
     elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dist, device="cuda" if backend == "nccl" else "cpu")
+    elapsed = sharding.max_over_ranks(elapsed, dist, device=red_dev)
 
-    # ---- parity: one more (untimed) pass, every final picture against the reference decoder's MD5 right after its
-    # batch (the decoder recycles picture ids, so the check cannot wait): the first and last stream downloaded and
-    # hashed on the host, and every stream hashed on the device (skipped with --check-two-streams-only)
+    # ---- parity: one more (untimed) pass; after every step the picture every stream has just finished is hashed on
+    # the device and compared with the reference decoder's MD5 (the decoder recycles picture ids, so the check cannot
+    # wait); the first and last stream are also downloaded and hashed on the host
     bd = [sp.bit_depth_luma, sp.bit_depth_chroma, sp.bit_depth_chroma]
-    for b in range(nb):
+    checked = 0
+    for gg in range(g, g + npic):
+        W.step(gg)
         for c in range(C):
-            engs[c].reconstruct_prepared(prepared[b][c])
-        for t in members[b]:
-            pic = seq.pictures[t]
-            for s in sorted({0, S - 1}):
-                planes = engs[ctx_of[s]].download(ids[t][s])
-                got = [syntax.plane_md5(planes[c], bd[c]) for c in range(3)]
-                if got != pic.stage_md5[2]:
-                    raise SystemExit("bench: stream %d POC %d differs from the reference decoder's MD5" % (s, pic.poc))
-            for c in range(C if not args.check_two_streams_only else 0):
-                for s, got in zip(groups[c], engs[c].md5([ids[t][s] for s in groups[c]])):
-                    if got != pic.stage_md5[2]:
-                        raise SystemExit("bench: stream %d POC %d differs from the reference decoder's MD5 (device hash)" % (s, pic.poc))
+            m = W.members(c, gg)
+            want = [W.seqs[W.seed_of[s]].pictures[t].stage_md5[2] for s, t in m]
+            for (s, t), w in zip(m, want):
+                if s in (0, S - 1):
+                    planes = engs[c].download(W.pic_id(s, t))
+                    if [syntax.plane_md5(planes[k], bd[k]) for k in range(3)] != w:
+                        raise SystemExit("bench: stream %d picture %d differs from the reference decoder's MD5" % (s, t))
+            if not args.check_two_streams_only:
+                for (s, t), got, w in zip(m, engs[c].md5([W.pic_id(s, t) for s, t in m]), want):
+                    if got != w:
+                        raise SystemExit("bench: stream %d picture %d differs from the reference decoder's MD5 (device hash)" % (s, t))
+                    checked += 1
+    g += npic
 
-    # ---- per-kernel time with HIP events on the engine's stream (one extra, untimed step) ----
-    # (first context only, scaled by nothing: with several contexts the kernels of different contexts overlap,
-    # so per-kernel times are taken from a single-context pass over that context's streams)
+    # ---- per-kernel time with HIP events on the engine's stream (one extra, untimed pass of context 0 alone: with
+    # several contexts the kernels of different contexts overlap, so their times are taken without the others) ----
+    eng = engs[0]
     eng.profile_enable(True)
-    for b in range(nb):
-        eng.reconstruct_prepared(prepared[b][0])
+    for gg in range(g, g + npic):
+        p = W.prepared(0, gg)
+        if p is not None:
+            eng.reconstruct_prepared(p)
     prof = eng.profile_read()
     eng.profile_enable(False)
     S_prof = len(groups[0])
-    kb = kernel_bytes(seq, stats, sao_flags)
+    kb = dict.fromkeys(KERNELS, 0)
+    for s in groups[0]:
+        k = W.seed_of[s]
+        for t, pic in enumerate(W.seqs[k].pictures):
+            one = kernel_bytes(sp, W.stats[k][t], bool(pic.pic_params.sao_luma or pic.pic_params.sao_chroma))
+            for name in KERNELS:
+                kb[name] += one[name]
     kernels = {}
     for name, nbytes in kb.items():
         ms, launches = prof[name]
         kernels[name] = {"ms_per_step": round(ms, 4), "launches": int(launches),
-                         "alg_gbps": round(nbytes * S_prof / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}
+                         "alg_gbps": round(nbytes / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}
     dom = max(kb, key=lambda k: prof[k][0])
     dom_ms, dom_launches = prof[dom]
-    achieved = kb[dom] * S_prof / (dom_ms * 1e-3) / 1e9
+    achieved = kb[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     gpu_ms = sum(prof[k][0] for k in kb)
 
     # HBM traffic of the dominant kernel: not measurable from inside the process; taken from the committed PMC
@@ -311,31 +401,12 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             tj = json.load(f)
-        if tj.get("streams") == S_prof and tj.get("fixture") == args.fixture and dom in tj.get("kernels", {}):
+        if tj.get("streams") == S_prof and tj.get("fixture") == args.fixture and tj.get("clips", 1) == len(seqs) and dom in tj.get("kernels", {}):
             traffic = tj["kernels"][dom]["bytes_per_launch"]
     except (OSError, ValueError):
         pass
 
-    # ---- syntax hand-over (untimed for `value`): the packed pictures cross the host link again ----
-    # Two steps in which every picture is marked for upload before its batch is submitted: the engine copies a
-    # batch's pictures from their pinned buffers on its copy streams, beside the previous batch's kernels, and
-    # expands the run-length coded records.  (Packing itself, host work of the decoder, is not repeated.)
-    handover = None
-    if not args.no_handover:
-        up_bytes = sum(syns[t][0].stats()[29] for t in range(npic))
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(2):
-            for b in range(nb):
-                for c in range(C):
-                    engs[c].upload_prepared(prepared[b][c])
-                    engs[c].reconstruct_prepared(prepared[b][c])
-        sync()
-        t_both = (time.perf_counter() - t0) / 2
-        handover = {"bytes_per_frame": up_bytes // npic, "with_reconstruction_frames_per_s": round(npic * S / t_both, 1),
-                    "link_gbps": round(up_bytes * S / t_both / 1e9, 2)}
-
-    frames_total = sharding.sum_over_ranks(npic * S * args.steps, dist, device="cuda" if backend == "nccl" else "cpu")
+    frames_total = sharding.sum_over_ranks(npic * S * args.steps, dist, device=red_dev)
     value = frames_total / elapsed
     result = {
         "metric": "1080p_ra_reconstructed_frames_per_s",
@@ -350,31 +421,78 @@ def main():
         "vs_baseline": None,
         "dtype": "u8" if sp.bit_depth_luma <= 8 else "u16",
         "data": "synthetic",
-        "config": {"workload": "%dx%d %d-frame RA stream (encoder_randomaccess_main.cfg), %d independent streams per GPU, "
-                               "stream-sharded, no collectives" % (sp.width, sp.height, npic, S),
-                   "streams_per_gpu": S, "contexts_per_gpu": C, "frames_per_stream": npic, "batches_per_stream_pass": nb,
-                   "upload_ring": bool(args.upload_ring), "md5_exact": True, "md5_checked_streams": min(S, 2) if args.check_two_streams_only else S},
-        "recon_alg_gbps": round(alg_bytes_stream * S * args.steps / elapsed / 1e9, 2),
-        "recon_alg_gbps_gpu_time": round(alg_bytes_stream * S_prof / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None,
-        "alg_bytes_per_frame": alg_bytes_stream // npic,
+        "config": {"workload": "%dx%d %d-frame RA streams (encoder_randomaccess_main.cfg) of %d different clips, %d independent streams per GPU "
+                               "over %d engine contexts, %s, stream-sharded, no collectives"
+                               % (sp.width, sp.height, npic, len(seqs), S, C,
+                                  "every stream at its own decoding position" if args.stagger else
+                                  "the streams of a context at one decoding position, the contexts %d pictures apart" % (npic // C)),
+                   "streams_per_gpu": S, "contexts_per_gpu": C, "frames_per_stream": npic, "clips": len(seqs), "staggered": bool(args.stagger),
+                   "upload_ring": bool(args.upload_ring), "md5_exact": True, "md5_checked_pictures": checked if not args.check_two_streams_only else 2 * npic},
+        "recon_alg_gbps": round(sum(alg_bytes_stream) * args.steps / elapsed / 1e9, 2),
+        "recon_alg_gbps_gpu_time": round(sum(alg_bytes_stream[s] for s in groups[0]) / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None,
+        "alg_bytes_per_frame": sum(alg_bytes_stream) // (npic * S),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                     "alg_bytes_per_launch": int(kb[dom] * S_prof / max(dom_launches, 1)),
+                     "alg_bytes_per_launch": int(kb[dom] / max(dom_launches, 1)),
                      "launches_per_step": int(dom_launches), "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 3),
                      "pictures_per_launch": S_prof, "timed_in": "a pass of one context alone (HIP events on its stream)"},
         "kernels": kernels,
+        "packer_us_per_picture": round(W.pack_s / max(W.pack_n, 1) * 1e6, 1),
     }
-    if handover is not None:
-        result["handover"] = handover
+
+    if not args.no_extras and world == 1:
+        # ---- syntax hand-over (never `value`): the packed pictures cross the host link again ----
+        # Two passes in which every picture is marked for upload before its batch is submitted: the engine copies a
+        # batch's pictures from their pinned buffers on its copy streams, beside the previous batch's kernels, and
+        # expands the run-length coded records.  (Packing itself, host work of the decoder, is not repeated.)
+        if not args.no_handover:
+            up_bytes = sum(W.syns[t][s].stats()[29] for t in range(npic) for s in range(S))
+            sync()
+            t0 = time.perf_counter()
+            for gg in range(g, g + 2 * npic):
+                W.step(gg, upload=True)
+            sync()
+            t_both = (time.perf_counter() - t0) / 2
+            g += 2 * npic
+            result["handover"] = {"bytes_per_frame": up_bytes // (npic * S), "with_reconstruction_frames_per_s": round(npic * S / t_both, 1),
+                                  "link_gbps": round(up_bytes / t_both / 1e9, 2)}
+        # ---- fewer streams: 1 and 8 streams of context 0 alone (what one decoder process, or 64 streams over 8 GPUs
+        # = 8 per GPU, get out of the device), and all streams each at its own position ----
+        side = {}
+        for n_small in (1, 8):
+            if n_small <= len(groups[0]):
+                sub = groups[0][:n_small]
+                preps = [engs[0].prepare_batch([W.syns[t][s] for s in sub], [W.pic_id(s, t) for s in sub]) for t in range(npic)]
+                for p in preps:
+                    engs[0].reconstruct_prepared(p)
+                engs[0].synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    for p in preps:
+                        engs[0].reconstruct_prepared(p)
+                engs[0].synchronize()
+                side["streams_%d_frames_per_s" % n_small] = round(2 * npic * n_small / (time.perf_counter() - t0), 1)
+        if not args.stagger and S >= 2 * C:
+            W.set_offsets(True)
+            gg = 0
+            while gg < W.max_off:
+                W.step(gg)
+                gg += 1
+            gg = run_passes(gg, 1)
+            sync()
+            t0 = time.perf_counter()
+            gg = run_passes(gg, 2)
+            sync()
+            side["every_stream_at_its_own_position_frames_per_s"] = round(2 * npic * S / (time.perf_counter() - t0), 1)
+        result["fewer_streams"] = side
+        e2e = end_to_end(local_rank)
+        if e2e is not None:
+            result["end_to_end"] = e2e
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(result))
-    for row in syns:
-        for y in row:
-            y.close()
-    for e in engs:
-        e.close()
+    W.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -5,6 +5,7 @@ libhevcrecon.so (HIP, gfx950); nothing here touches samples except to copy
 them in and out of numpy arrays.
 """
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -23,6 +24,7 @@ class Syntax:
         self.lib = engine.lib
         self.h = handle
         self.poc = None
+        self.pack_seconds = 0.0
 
     def pack(self, pic):
         """begin + add_ctu for every CTU + finish (which queues the upload)."""
@@ -36,9 +38,16 @@ class Syntax:
         order = range(pic.nctu)
         if getattr(pic, "tiles", None) is not None:  # CTUs go in coding order (tile scan)
             order = sorted(range(pic.nctu), key=lambda a: int(pic.tiles[a, 0]))
+        add, check = lib.hevcrecon_syntax_add_ctu, self.engine._check
+        t0 = time.perf_counter()
         for a in order:
-            self.engine._check(lib.hevcrecon_syntax_add_ctu(self.h, a, C.byref(ctus[a])), "hevcrecon_syntax_add_ctu")
-        self.engine._check(lib.hevcrecon_syntax_finish(self.h, C.byref(pic.pic_params)), "hevcrecon_syntax_finish")
+            rc = add(self.h, a, C.byref(ctus[a]))
+            if rc:
+                check(rc, "hevcrecon_syntax_add_ctu")
+        check(lib.hevcrecon_syntax_finish(self.h, C.byref(pic.pic_params)), "hevcrecon_syntax_finish")
+        # host time of packing this picture: the add_ctu calls and finish (with the foreign-function overhead of one
+        # call per CTU, about a microsecond each)
+        self.pack_seconds = time.perf_counter() - t0
         self.poc = pic.poc
         return self
 

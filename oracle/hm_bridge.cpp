@@ -10,7 +10,7 @@
 //   TComLoopFilter::loopFilterPic   TLibDecoder/TDecGop.cpp:181     (deblocking)
 //   TComSampleAdaptiveOffset::SAOProcess  TLibDecoder/TDecGop.cpp:199 (SAO)
 //   TComSampleAdaptiveOffset::PCMLFDisableProcess  TLibDecoder/TDecGop.cpp:200 (restoring lossless units after SAO)
-//   TComPic::compressMotion         TLibDecoder/TDecGop.cpp:210     (observation point only)
+//   TComPic::compressMotion         TLibDecoder/TDecGop.cpp:210     (runs beside the GPU; the picture is fetched after it)
 //
 // Modes (environment variable HEVCRECON_MODE):
 //   unset / "ref"  : behave exactly like the reference.
@@ -448,9 +448,20 @@ struct Bridge {
     }
     if (api.syntax_finish(syn, &pp)) fail("hevcrecon_syntax_finish");
     int id = pic_id(pic);
-    if (api.reconstruct(ctx, syn, id)) fail("hevcrecon_reconstruct");
+    if (api.reconstruct(ctx, syn, id)) fail("hevcrecon_reconstruct");  // queued: the GPU works from here on
+    pending = pic;
+  }
+
+  // The picture is fetched only when the decoder is about to need it: after TComPic::compressMotion
+  // (TLibDecoder/TDecGop.cpp:210; TLibCommon/TComMotionInfo.cpp:330-351), so that the host's sub-sampling of the
+  // motion field runs beside the GPU's reconstruction instead of after it.  The packer copied the motion vectors
+  // when the CTUs were added, before compressMotion changes them.
+  TComPic *pending = NULL;
+  void engine_fetch(TComPic *pic) {
+    if (pending != pic) return;
+    pending = NULL;
     TComPicYuv *yuv = pic->getPicYuvRec();
-    if (api.picture_download(ctx, id, yuv->getLumaAddr(), yuv->getCbAddr(), yuv->getCrAddr(), yuv->getStride(),
+    if (api.picture_download(ctx, pic_id(pic), yuv->getLumaAddr(), yuv->getCbAddr(), yuv->getCrAddr(), yuv->getStride(),
                              yuv->getCStride()))
       fail("hevcrecon_picture_download");
   }
@@ -498,4 +509,5 @@ Void TComPic::compressMotion() {
     b.write_picture(this);  // before the motion field is sub-sampled
   }
   compressMotion_ref();
+  if (b.mode == MODE_ENGINE) b.engine_fetch(this);
 }

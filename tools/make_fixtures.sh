@@ -37,8 +37,17 @@ $E -c $cfg/encoder_randomaccess_main.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f
 $E -c $cfg/encoder_randomaccess_he10.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 5 -q 6 -b pcm_240.bin -o /dev/null --SEIpictureDigest=1 --PCMEnabledFlag=1 --PCMFilterDisableFlag=1 > pcm_240.enc.log &
 $E -c $cfg/encoder_lowdelay_P_main.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 4 -q 6 -b pcmlf_240.bin -o /dev/null --SEIpictureDigest=1 --PCMEnabledFlag=1 --PCMFilterDisableFlag=0 > pcmlf_240.enc.log &
 $E -c $cfg/encoder_randomaccess_main.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 60 -b ra_main_1080.bin -o /dev/null --SEIpictureDigest=1 > ra_main_1080.enc.log &
-$E -c $cfg/encoder_randomaccess_he10.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 25 -b ra_he10_1080.bin -o /dev/null --SEIpictureDigest=1 > ra_he10_1080.enc.log &
+$E -c $cfg/encoder_randomaccess_he10.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 60 -b ra_he10_1080.bin -o /dev/null --SEIpictureDigest=1 > ra_he10_1080.enc.log &
+# all-intra: 16 frames as a syntax dump (4 MB), all 60 frames as a bitstream only (11 MB, kept beside the compiled
+# reference under oracle/_ref/fixtures, not committed: decoded through the reference decoder's CLI with the engine behind it)
 $E -c $cfg/encoder_intra_main.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 16 -b intra_main_1080.bin -o /dev/null --SEIpictureDigest=1 > intra_main_1080.enc.log &
+$E -c $cfg/encoder_intra_main.cfg -i c1080.yuv -wdt 1920 -hgt 1080 -fr 30 -f 60 -b intra_main_1080_f60.bin -o /dev/null --SEIpictureDigest=1 > intra_main_1080_f60.enc.log &
+# the multi-stream benchmark's other seven 1080p random-access streams: clips of seeds 20240607 + k
+for k in 1 2 3 4 5 6 7; do
+  ( python "$root/tools/gen_clip.py" 1920 1080 60 $((20240607 + k)) c1080_s$k.yuv
+    $E -c $cfg/encoder_randomaccess_main.cfg -i c1080_s$k.yuv -wdt 1920 -hgt 1080 -fr 30 -f 60 -b ra_main_1080_s$k.bin -o /dev/null --SEIpictureDigest=1 > ra_main_1080_s$k.enc.log
+    rm -f c1080_s$k.yuv ) &
+done
 # option sweep: bitstreams only, decoded through the reference decoder's CLI with the engine behind it
 sw() { name=$1; shift; $E "$@" -wdt 416 -hgt 240 -fr 30 -b sweep_$name.bin -o /dev/null --SEIpictureDigest=1 > sweep_$name.enc.log; }
 sw dqp -c $cfg/encoder_randomaccess_main.cfg -i c240.yuv -f 5 --MaxDeltaQP=4 --MaxCuDQPDepth=2 --CbQpOffset=3 --CrQpOffset=-4 --DeblockingFilterControlPresent=1 --LoopFilterBetaOffset_div2=2 --LoopFilterTcOffset_div2=-1 &
@@ -49,7 +58,7 @@ sw lb -c $cfg/encoder_lowdelay_main.cfg -i f240.yuv -f 6 -q 30 &
 wait
 for n in dqp q22 q45 tu lb; do cp sweep_$n.bin "$root/tests/golden/"; done
 D="$root/oracle/_ref/TAppDecoderBridge"
-for s in lowdelay_P_main_240 randomaccess_main_240 randomaccess_he10_240 intra_main_240 scalinglist_240 lossless_240 pcm_240 pcmlf_240 wpp_240 wpb_240 cip_240 bd12_240 slices_240 tiles_240 ra_main_1080 ra_he10_1080 intra_main_1080; do
+for s in lowdelay_P_main_240 randomaccess_main_240 randomaccess_he10_240 intra_main_240 scalinglist_240 lossless_240 pcm_240 pcmlf_240 wpp_240 wpb_240 cip_240 bd12_240 slices_240 tiles_240 ra_main_1080 ra_he10_1080 intra_main_1080 intra_main_1080_f60 ra_main_1080_s1 ra_main_1080_s2 ra_main_1080_s3 ra_main_1080_s4 ra_main_1080_s5 ra_main_1080_s6 ra_main_1080_s7; do
   HEVCRECON_MODE=dump HEVCRECON_DUMP=$s.syn $D -b $s.bin > $s.dec.log
 done
 # the reference decoder's output files at other bit depths than the internal one (digest per frame, display order)
@@ -78,7 +87,9 @@ names = {"lowdelay_P_main_240": "lowdelay_P_main_416x240", "randomaccess_main_24
          "pcm_240": "pcm_416x240", "pcmlf_240": "pcmlf_416x240", "wpp_240": "wpp_416x240", "wpb_240": "wpb_416x240", "cip_240": "cip_416x240", "bd12_240": "bd12_416x240", "slices_240": "slices_416x240", "tiles_240": "tiles_416x240",
          "ra_main_1080": "randomaccess_main_1920x1080", "ra_he10_1080": "randomaccess_he10_1920x1080",
          "intra_main_1080": "intra_main_1920x1080"}
+names.update({"ra_main_1080_s%d" % k: "randomaccess_main_1920x1080_s%d" % k for k in range(1, 8)})
 keys = {"ra_main_1080": "randomaccess_main_1080", "ra_he10_1080": "randomaccess_he10_1080"}
+keys.update({"ra_main_1080_s%d" % k: "randomaccess_main_1080_s%d" % k for k in range(1, 8)})
 md5 = {}
 for src, dst in names.items():
     syntax.strip_planes_and_compress("work/%s.syn" % src, "tests/golden/%s.syn.xz" % dst, preset=6)
@@ -93,4 +104,18 @@ json.dump(md5, open("tests/golden/hm_md5.json", "w"), indent=0)
 for b in ["lowdelay_P_main_240", "randomaccess_main_240", "randomaccess_he10_240", "intra_main_240", "scalinglist_240", "lossless_240", "pcm_240", "pcmlf_240", "wpp_240", "wpb_240", "cip_240", "bd12_240", "slices_240", "tiles_240"]:
     shutil.copy("work/%s.bin" % b, "tests/golden/%s.bin" % b)
 shutil.copy("work/ra_main_1080.bin", "tests/golden/randomaccess_main_1080.bin")
+shutil.copy("work/ra_he10_1080.bin", "tests/golden/randomaccess_he10_1080.bin")
+# the 60-frame all-intra stream: digests only (from its decoder log), bitstream beside the compiled reference
+rows = []
+for line in open("work/intra_main_1080_f60.dec.log", errors="replace"):
+    m = re.search(r"POC\s+(\d+).*\[MD5:([0-9a-f]{32}),([0-9a-f]{32}),([0-9a-f]{32}),\((\w+)\)\]", line)
+    if m:
+        assert m.group(5) == "OK"
+        rows.append([int(m.group(1)), m.group(2), m.group(3), m.group(4)])
+md5 = json.load(open("tests/golden/hm_md5.json"))
+md5["intra_main_1080_f60"] = rows
+json.dump(md5, open("tests/golden/hm_md5.json", "w"), indent=0)
+import os
+os.makedirs("oracle/_ref/fixtures", exist_ok=True)
+shutil.copy("work/intra_main_1080_f60.bin", "oracle/_ref/fixtures/intra_main_1080_f60.bin")
 PY
