@@ -49,8 +49,23 @@ class PicParams(C.Structure):
         ("ref_pic_id", (C.c_int32 * MAX_REFS) * 2),
         ("ref_poc", (C.c_int32 * MAX_REFS) * 2),
         ("constrained_intra_pred", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("no_loop_filter_across_tiles", C.c_int32),
+        ("reserved", C.c_int32 * 6),
     ]
+
+
+class SliceParams(C.Structure):
+    _fields_ = [
+        ("start_addr", C.c_uint32),
+        ("deblocking_disable", C.c_int32),
+        ("beta_offset_div2", C.c_int32),
+        ("tc_offset_div2", C.c_int32),
+        ("cb_qp_delta_slice", C.c_int32),
+        ("cr_qp_delta_slice", C.c_int32),
+        ("loop_filter_across_slices", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
 
 # size of the structure in dumps of format 1 (before constrained_intra_pred + reserved were appended)
 PIC_PARAMS_SIZE_V1 = (13 + 2 * MAX_REFS * 2) * 4
@@ -118,6 +133,7 @@ EXPORTS = {
     "hevcrecon_syntax_begin": (C.c_int, [_P]),
     "hevcrecon_syntax_set_scaling_lists": (C.c_int, [_P, C.c_void_p]),
     "hevcrecon_syntax_set_pred_weights": (C.c_int, [_P, C.c_void_p]),
+    "hevcrecon_syntax_set_slices": (C.c_int, [_P, C.c_int, C.c_void_p]),
     "hevcrecon_syntax_add_ctu": (C.c_int, [_P, C.c_int, C.POINTER(CtuSyntax)]),
     "hevcrecon_syntax_finish": (C.c_int, [_P, C.POINTER(PicParams)]),
     "hevcrecon_syntax_upload": (C.c_int, [_P]),

@@ -16,6 +16,7 @@
 //                                neighbouring CTUs whose intra blocks its own blocks read)
 //   * McTile  mc_tile[3][...] / McBlk mc_blk[...]  regions with uniform / mixed motion
 //   * SaoCtu  sao[nCtu*3]        SAO parameters per CTU and component
+//   * CtuInfo ctu_info[nCtu]     only for pictures with per-slice filter parameters or uncrossed slice / tile boundaries
 // Sample planes are uint8 for 8-bit sequences and uint16 otherwise, with no margin: kernels clamp
 // reference coordinates instead of reading the reference's 80-sample replicated border.
 #ifndef HEVCRECON_COMMON_H
@@ -135,6 +136,18 @@ struct SaoCtu {
   int8_t pad[2];
 };
 
+// Per-CTU view of the slice and tile structure, present only for pictures whose slices differ in their parameters
+// or whose slices / tiles are not filtered across (slices end at CTU boundaries).
+#define CI_DEBLOCK_OFF 0x01 /* the CTU's slice has deblocking disabled */
+#define CI_EDGE_LEFT 0x02   /* the CTU's left edge may be deblocked (neighbour in reach of the slice / tile rules) */
+#define CI_EDGE_TOP 0x04    /* the same for its top edge */
+struct CtuInfo {
+  int8_t beta_off_div2, tc_off_div2; /* of the CTU's slice */
+  uint8_t flags;                     /* CI_* */
+  uint8_t sao_avail;                 /* SAO may classify against samples of the neighbouring CTU: bit 0 left, 1 right,
+                                        2 above, 3 below, 4 above-left, 5 above-right, 6 below-left, 7 below-right */
+};
+
 struct SeqInfo {
   int32_t w, h, cw, ch;
   int32_t uw, uh; /* picture size in 4x4 units */
@@ -173,6 +186,7 @@ struct PicJob {
   uint32_t *ctu_done;         /* one word per CTU (raster), zero when the batch starts: set by the intra kernel once the
                                  CTU's intra blocks are in the picture */
   const SaoCtu *sao;
+  const CtuInfo *ctu_info;      /* NULL: one set of filter parameters, every boundary inside the picture is crossed */
   const ScalingTables *scaling; /* NULL: flat de-quantisation */
   const WpTables *wp;           /* NULL: default (un)weighted prediction */
   int32_t slice_type; /* 0 B, 1 P, 2 I */

@@ -181,7 +181,7 @@ struct hevcrecon_syntax {
   bool expanded = false;       // rec4 has been expanded from the uploaded runs
   int64_t last_batch = -1;     // last batch whose kernels read the device copy
   int64_t upload_seq = -1;     // number of the batch of copies that carried the last upload
-  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_mct[3] = {0, 0, 0}, off_mcb = 0, off_scal = 0, off_wp = 0;
+  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_ctui = 0, off_mct[3] = {0, 0, 0}, off_mcb = 0, off_scal = 0, off_wp = 0;
   bool uploaded = false;
   std::string err;
 };
@@ -628,6 +628,16 @@ extern "C" int hevcrecon_syntax_set_pred_weights(hevcrecon_syntax *s, const hevc
   return 0;
 }
 
+extern "C" int hevcrecon_syntax_set_slices(hevcrecon_syntax *s, int n, const hevcrecon_slice_params *slices) {
+  if (!s) return 1;
+  if (!s->pk.set_slices(n, slices)) {
+    s->err = s->pk.error;
+    s->pk.error.clear();  // a refused table leaves the picture as it was
+    return fail(s->ctx, s->err);
+  }
+  return 0;
+}
+
 extern "C" int hevcrecon_syntax_add_ctu(hevcrecon_syntax *s, int ctu_addr, const hevcrecon_ctu_syntax *ctu) {
   if (!s || !ctu) return 1;
   if (!s->pk.add_ctu(ctu_addr, ctu)) {
@@ -675,6 +685,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   s->off_lvlc = place(k.lvl_counts.size() * sizeof(uint16_t));
   s->off_wave = place(k.wave_off.size() * sizeof(int32_t));
   s->off_sao = place(k.sao.size() * sizeof(SaoCtu));
+  s->off_ctui = place(k.ctu_info.size() * sizeof(CtuInfo));
   for (int i = 0; i < 3; i++) s->off_mct[i] = place(k.mc_tile[i].size() * sizeof(McTile));
   s->off_mcb = place(k.mc_blk.size() * sizeof(McBlk));
   s->off_scal = place(sizeof(ScalingTables));
@@ -719,6 +730,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   std::memcpy(s->up_host + s->off_lvlc, k.lvl_counts.data(), k.lvl_counts.size() * sizeof(uint16_t));
   std::memcpy(s->up_host + s->off_wave, k.wave_off.data(), k.wave_off.size() * sizeof(int32_t));
   std::memcpy(s->up_host + s->off_sao, k.sao.data(), k.sao.size() * sizeof(SaoCtu));
+  std::memcpy(s->up_host + s->off_ctui, k.ctu_info.data(), k.ctu_info.size() * sizeof(CtuInfo));
   for (int i = 0; i < 3; i++) std::memcpy(s->up_host + s->off_mct[i], k.mc_tile[i].data(), k.mc_tile[i].size() * sizeof(McTile));
   std::memcpy(s->up_host + s->off_mcb, k.mc_blk.data(), k.mc_blk.size() * sizeof(McBlk));
   std::memcpy(s->up_host + s->off_scal, &k.scaling, sizeof(ScalingTables));
@@ -903,11 +915,18 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
     if (j.n_waves > max_levels) max_levels = j.n_waves;
     j.ctu_done = ws.sync_dev + kSyncHead + (size_t)i * s.ctus_w * s.ctus_h;
     j.sao = (const SaoCtu *)(y->up_dev + y->off_sao);
+    j.ctu_info = k.ctu_info.empty() ? nullptr : (const CtuInfo *)(y->up_dev + y->off_ctui);
     j.scaling = k.use_scaling ? (const ScalingTables *)(y->up_dev + y->off_scal) : nullptr;
     j.wp = k.use_wp ? (const WpTables *)(y->up_dev + y->off_wp) : nullptr;
     any_wp = any_wp || k.use_wp;
     j.slice_type = k.pp.slice_type;
-    j.deblock_disable = k.pp.deblocking_disable;
+    // with a slice table the picture is deblocked unless every slice says no (the kernel then looks at each CTU's slice)
+    bool deblock_off = k.pp.deblocking_disable != 0;
+    if (!k.slices.empty()) {
+      deblock_off = true;
+      for (size_t q = 0; q < k.slices.size(); q++) deblock_off = deblock_off && k.slices[q].deblocking_disable;
+    }
+    j.deblock_disable = deblock_off ? 1 : 0;
     j.beta_off_div2 = k.pp.beta_offset_div2;
     j.tc_off_div2 = k.pp.tc_offset_div2;
     j.cb_off_pps = k.pp.cb_qp_offset_pps;
@@ -919,7 +938,7 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
     j.has_bypass = k.has_bypass ? 1 : 0;
     j.has_pcm = k.has_pcm ? 1 : 0;
     j.error_flag = c->error_flag_dev;
-    any_deblock = any_deblock || !k.pp.deblocking_disable;
+    any_deblock = any_deblock || !deblock_off;
   }
   bool uploaded_any = false;
   {  // hand-over of the pictures whose device copy is stale

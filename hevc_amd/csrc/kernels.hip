@@ -1711,6 +1711,17 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
     }
     if (rel != pe) return;
   }
+  // Slices with parameters of their own, slices or tiles that are not filtered across: the CTU holding the edge's Q
+  // side decides (pcCU->getSlice() and m_stLFCUParam.bLeftEdge / bTopEdge of TComLoopFilter::xSetLoopfilterParam,
+  // TLibCommon/TComLoopFilter.cpp:363-419; slices end at CTU boundaries)
+  int tc_off_div2 = J.tc_off_div2, beta_off_div2 = J.beta_off_div2;
+  if (J.ctu_info) {
+    const CtuInfo ci = J.ctu_info[(y >> 6) * s.ctus_w + (x >> 6)];
+    if (ci.flags & CI_DEBLOCK_OFF) return;
+    if ((pos & 63) == 0 && !(ci.flags & (DIR == 0 ? CI_EDGE_LEFT : CI_EDGE_TOP))) return;
+    tc_off_div2 = ci.tc_off_div2;
+    beta_off_div2 = ci.beta_off_div2;
+  }
   const int bs = boundary_strength(J, P, Q, tu_edge);
   if (!bs) return;
   // a side that belongs to a lossless coding unit is left as it is (bPartPNoFilter / bPartQNoFilter,
@@ -1719,8 +1730,8 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
   const int qp = (P.qp + Q.qp + 1) >> 1;
   {
     const int scale = 1 << (s.bd_y - 8), maxv = (1 << s.bd_y) - 1;
-    const int tc = kTc[clip3i(0, 53, qp + 2 * (bs - 1) + 2 * J.tc_off_div2)] * scale;
-    const int beta = kBeta[clip3i(0, 51, qp + 2 * J.beta_off_div2)] * scale;
+    const int tc = kTc[clip3i(0, 53, qp + 2 * (bs - 1) + 2 * tc_off_div2)] * scale;
+    const int beta = kBeta[clip3i(0, 51, qp + 2 * beta_off_div2)] * scale;
     const int step = DIR == 0 ? 1 : s.stride_y, line = DIR == 0 ? s.stride_y : 1;
     HR_GLOBAL pel_t *sp = (HR_GLOBAL pel_t *)J.rec[0] + (size_t)y * s.stride_y + x;
     int m[4][8];  // m[k][0..3] = p3..p0, m[k][4..7] = q0..q3 of line k
@@ -1822,7 +1833,7 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
     for (int c = 0; c < 2; c++) {
       int qc = qp + (c == 0 ? J.cb_off_pps : J.cr_off_pps);
       qc = qc < 0 ? qc : (qc > 57 ? qc - 6 : kChromaScale[qc]);
-      const int tc = kTc[clip3i(0, 53, qc + 2 + 2 * J.tc_off_div2)] * scale;
+      const int tc = kTc[clip3i(0, 53, qc + 2 + 2 * tc_off_div2)] * scale;
       HR_GLOBAL pel_t *sp = (HR_GLOBAL pel_t *)J.rec[1 + c] + (size_t)(y >> 1) * s.stride_c + (x >> 1);
 #pragma unroll
       for (int k = 0; k < 2; k++) {
@@ -1923,6 +1934,34 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
 #pragma unroll
       for (int i = 0; i < 16; i++)
         if (x + i == pw - 1) v[i] = sample(pc, i);
+    }
+  }
+  if (J.ctu_info && eo) {
+    // Slices or tiles that are not filtered across (TComSampleAdaptiveOffset::processSaoBlock,
+    // TLibCommon/TComSampleAdaptiveOffset.cpp:592-809): a sample is classified only when both neighbours along the
+    // class direction lie in its own CTU or in a neighbouring CTU that may be used; the others stay as they are.
+    // Picture borders are unusable neighbours in the same table.
+    const int cs = comp ? 32 : 64;
+    const unsigned am = J.ctu_info[(y >> csh) * s.ctus_w + (x >> csh)].sao_avail;
+    auto usable = [&](int ox, int oy) -> bool {
+      if (ox == 0 && oy == 0) return true;
+      const int bit = oy == 0 ? (ox < 0 ? 0 : 1) : ox == 0 ? (oy < 0 ? 2 : 3) : (oy < 0 ? (ox < 0 ? 4 : 5) : (ox < 0 ? 6 : 7));
+      return ((am >> bit) & 1u) != 0;
+    };
+    const bool top = (y & (cs - 1)) == 0, bottom = (y & (cs - 1)) == cs - 1 || y == ph - 1;
+    const int oy_a = dy && top ? -1 : 0, oy_b = dy && bottom ? 1 : 0;  // neighbour a lies towards (-dx,-dy), b towards (+dx,+dy)
+    const bool ok_mid = usable(0, oy_a) && usable(0, oy_b);
+    const bool at_left = (x & (cs - 1)) == 0;  // the lane's first sample is the first of its CTU's row
+    int i_last = ((x + 16) & (cs - 1)) == 0 ? 15 : -1;  // index of the last sample of the CTU's row, when the lane holds it
+    if (x + 16 >= pw) i_last = pw - 1 - x;
+    const bool ok_first = usable(dx == 1 ? -1 : 0, oy_a) && usable(dx == -1 ? -1 : 0, oy_b);
+    const bool ok_last = usable(dx == -1 ? 1 : 0, oy_a) && usable(dx == 1 ? 1 : 0, oy_b);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const bool first = i == 0 && at_left, last = i == i_last;
+      // (a CTU row is at least 16 samples long here, so no sample is both)
+      const bool ok = first ? ok_first : (last ? ok_last : ok_mid);
+      if (!ok) v[i] = sample(pc, i);
     }
   }
   if (J.has_bypass) {

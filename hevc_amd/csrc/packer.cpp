@@ -67,8 +67,106 @@ void PackedPicture::begin(const SeqInfo &s) {
   next_ctu = 0;
   ctu_order.assign((size_t)s.ctus_w * s.ctus_h, -1);
   ctu_tile.assign((size_t)s.ctus_w * s.ctus_h, 0);
+  slices.clear();
+  ctu_slice.assign((size_t)s.ctus_w * s.ctus_h, 0);
+  ctu_info.clear();
   finished = false;
   error.clear();
+}
+
+bool PackedPicture::set_slices(int n, const hevcrecon_slice_params *sl) {
+  if (finished || next_ctu != 0) {
+    error = "the slice table must be set after hevcrecon_syntax_begin and before the first CTU";
+    return false;
+  }
+  if (n < 0 || (n > 0 && !sl)) {
+    error = "bad slice table";
+    return false;
+  }
+  for (int i = 0; i < n; i++)
+    if (sl[i].beta_offset_div2 < -6 || sl[i].beta_offset_div2 > 6 || sl[i].tc_offset_div2 < -6 || sl[i].tc_offset_div2 > 6 ||
+        sl[i].cb_qp_delta_slice < -12 || sl[i].cb_qp_delta_slice > 12 || sl[i].cr_qp_delta_slice < -12 || sl[i].cr_qp_delta_slice > 12) {
+      error = "slice parameter out of range";
+      return false;
+    }
+  slices.assign(sl, sl + n);
+  return true;
+}
+
+const hevcrecon_slice_params *PackedPicture::slice_at(uint32_t start) const {
+  for (size_t i = 0; i < slices.size(); i++)
+    if (slices[i].start_addr == start) return &slices[i];
+  return nullptr;
+}
+
+// What the in-loop filter kernels need to know per CTU when slices carry their own parameters or boundaries are not
+// crossed.  Deblocking: TComLoopFilter::xSetLoopfilterParam (TLibCommon/TComLoopFilter.cpp:363-419) over
+// TComDataCU::getPULeft / getPUAbove (TLibCommon/TComDataCU.cpp:1141-1238): the edge towards a neighbouring CTU is
+// filtered unless the CTU's slice does not filter across slice boundaries and the neighbour precedes that slice, or
+// tiles are not crossed and the neighbour belongs to another tile; parameters are those of the CTU's slice.
+// SAO: TComDataCU::setNDBFilterBlockBorderAvailability (TLibCommon/TComDataCU.cpp:3813-4166, one block per CTU) with
+// the tile sides of TComPic::createNonDBFilterInfo (TLibCommon/TComPic.cpp:301-327): a neighbouring block is usable
+// when it lies in the picture and either belongs to the same slice or the later of the two slices filters across its
+// boundaries, and no uncrossed tile boundary lies on the sides of the CTU it is reached over.
+bool PackedPicture::build_ctu_info() {
+  ctu_info.clear();
+  if (slices.empty() && !pp.no_loop_filter_across_tiles) return true;
+  const int W = seq.ctus_w, H = seq.ctus_h;
+  ctu_info.resize((size_t)W * H);
+  hevcrecon_slice_params dflt;
+  std::memset(&dflt, 0, sizeof(dflt));
+  dflt.deblocking_disable = pp.deblocking_disable;
+  dflt.beta_offset_div2 = pp.beta_offset_div2;
+  dflt.tc_offset_div2 = pp.tc_offset_div2;
+  dflt.cb_qp_delta_slice = pp.cb_qp_delta_slice;
+  dflt.cr_qp_delta_slice = pp.cr_qp_delta_slice;
+  dflt.loop_filter_across_slices = 1;
+  auto slice_of = [&](int a) -> const hevcrecon_slice_params & {
+    const hevcrecon_slice_params *sl = slices.empty() ? nullptr : slice_at(ctu_slice[a]);
+    return sl ? *sl : dflt;
+  };
+  const bool tiles_apart = pp.no_loop_filter_across_tiles != 0;
+  for (int a = 0; a < W * H; a++) {
+    const int cx = a % W, cy = a / W;
+    const hevcrecon_slice_params &me = slice_of(a);
+    CtuInfo ci;
+    ci.beta_off_div2 = (int8_t)me.beta_offset_div2;
+    ci.tc_off_div2 = (int8_t)me.tc_offset_div2;
+    ci.flags = me.deblocking_disable ? CI_DEBLOCK_OFF : 0;
+    auto edge_ok = [&](int n) {
+      if (!me.loop_filter_across_slices && (uint32_t)ctu_order[n] * 256u + 255u < ctu_slice[a]) return false;
+      if (tiles_apart && ctu_tile[n] != ctu_tile[a]) return false;
+      return true;
+    };
+    if (cx > 0 && edge_ok(a - 1)) ci.flags |= CI_EDGE_LEFT;
+    if (cy > 0 && edge_ok(a - W)) ci.flags |= CI_EDGE_TOP;
+    static const int kOx[8] = {-1, 1, 0, 0, -1, 1, -1, 1}, kOy[8] = {0, 0, -1, 1, -1, -1, 1, 1};
+    ci.sao_avail = 0;
+    for (int b = 0; b < 8; b++) {
+      const int nx = cx + kOx[b], ny = cy + kOy[b];
+      if (nx < 0 || ny < 0 || nx >= W || ny >= H) continue;
+      const int n = ny * W + nx;
+      if (ctu_slice[n] != ctu_slice[a]) {
+        const hevcrecon_slice_params &later = ctu_slice[n] > ctu_slice[a] ? slice_of(n) : me;
+        if (!later.loop_filter_across_slices) continue;
+      }
+      if (tiles_apart && ((kOx[b] && ctu_tile[a + kOx[b]] != ctu_tile[a]) || (kOy[b] && ctu_tile[a + kOy[b] * W] != ctu_tile[a]))) continue;
+      ci.sao_avail |= (uint8_t)(1 << b);
+    }
+    ctu_info[a] = ci;
+  }
+  // De-quantisation adds the picture's chroma offsets (PPS offset + the slice delta of the picture parameters) to the
+  // QP a transform block carries: blocks of a slice with other deltas carry the difference.
+  if (!slices.empty())
+    for (int i = 0; i < 4; i++)
+      for (size_t k = 0; k < tu[i].size(); k++) {
+        TuItem &t = tu[i][k];
+        if (!t.comp) continue;
+        const int a = (t.y >> 5) * W + (t.x >> 5);
+        const hevcrecon_slice_params &sl = slice_of(a);
+        t.qp = (int8_t)(t.qp + (t.comp == 1 ? sl.cb_qp_delta_slice - pp.cb_qp_delta_slice : sl.cr_qp_delta_slice - pp.cr_qp_delta_slice));
+      }
+  return true;
 }
 
 // Position in coding order of the 4x4 unit (ux, uy): CTUs in the order they were added (raster, or tile scan),
@@ -87,6 +185,20 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
   }
   ctu_order[addr] = next_ctu++;
   ctu_tile[addr] = ctu->tile_id;
+  ctu_slice[addr] = ctu->slice_start ? ctu->slice_start[0] : 0;
+  if (!slices.empty()) {
+    // per-slice parameters are kept per CTU: every partition inside the picture has to belong to the same slice
+    const int cx0 = (addr % seq.ctus_w) * 16, cy0 = (addr / seq.ctus_w) * 16;
+    for (int z = 0; z < 256 && ctu->slice_start; z++)
+      if (cx0 + kZ.x[z] < seq.uw && cy0 + kZ.y[z] < seq.uh && ctu->slice_start[z] != ctu_slice[addr]) {
+        error = "a slice table needs slices that end at CTU boundaries";
+        return false;
+      }
+    if (!slice_at(ctu_slice[addr])) {
+      error = "CTU of a slice that is not in the slice table";
+      return false;
+    }
+  }
   for (int c = 0; c < 3; c++) {
     SaoCtu &s = sao[(size_t)addr * 3 + c];
     s.type = (int8_t)ctu->sao_type[c];
@@ -449,6 +561,7 @@ bool PackedPicture::finish(const hevcrecon_pic_params *p) {
   std::vector<int32_t> cursor(wave_off.begin(), wave_off.end());
   for (size_t i = 0; i < ictu.size(); i++) sorted[cursor[ictu_wave[i] - 1]++] = ictu[i];
   ictu.swap(sorted);
+  if (!build_ctu_info()) return false;
   build_mc_lists();
   build_runs();
   n_rec4 = (int64_t)rec4.size();

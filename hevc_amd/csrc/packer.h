@@ -25,6 +25,13 @@ struct PackedPicture {
   std::vector<uint16_t> lvl_counts; // per CTU, per local level: number of blocks
   std::vector<int32_t> wave_off;    // n_waves + 1 offsets into ictu
   std::vector<SaoCtu> sao;
+  // Slices that differ in their parameters or are not filtered across (set before the first CTU; empty: the picture
+  // parameters hold for every slice), the slice every CTU belongs to (its start address), and what finish() derives
+  // from both and from the tiles for the kernels (empty when every boundary is crossed with one set of parameters)
+  std::vector<hevcrecon_slice_params> slices;
+  std::vector<uint32_t> ctu_slice;
+  std::vector<CtuInfo> ctu_info;
+  bool set_slices(int n, const hevcrecon_slice_params *sl);
   std::vector<McTile> mc_tile[3];   // filled by finish(): 64x64 / 32x32 / 16x16 regions predicted as one block
   std::vector<McBlk> mc_blk;        // filled by finish(): 16x16 regions predicted unit by unit
   bool has_bypass;                  // some coding unit is exempt from in-loop filtering (lossless, or IPCM with the filters off)
@@ -76,6 +83,8 @@ struct PackedPicture {
   void emit_tu(const hevcrecon_ctu_syntax *ctu, int comp, int z, int zcu, int x, int y, int log2n, int flags, uint32_t *off_out);
   void emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z, int zcu, int x, int y, int log2n, int mode);
   int coding_order(int ux, int uy) const;
+  const hevcrecon_slice_params *slice_at(uint32_t start) const;
+  bool build_ctu_info();
   void build_mc_lists();
   void split_mc(int x0, int y0, int level);
   int classify_mc(int x0, int y0, int size, McTile *out) const;

@@ -34,6 +34,8 @@ class Syntax:
             self.engine._check(lib.hevcrecon_syntax_set_scaling_lists(self.h, C.addressof(pic.scaling)), "hevcrecon_syntax_set_scaling_lists")
         if getattr(pic, "pred_weights", None) is not None:
             self.engine._check(lib.hevcrecon_syntax_set_pred_weights(self.h, C.addressof(pic.pred_weights)), "hevcrecon_syntax_set_pred_weights")
+        if getattr(pic, "slices", None) is not None:
+            self.engine._check(lib.hevcrecon_syntax_set_slices(self.h, len(pic.slices), C.addressof(pic.slices)), "hevcrecon_syntax_set_slices")
         ctus = pic.ctu_structs()
         order = range(pic.nctu)
         if getattr(pic, "tiles", None) is not None:  # CTUs go in coding order (tile scan)

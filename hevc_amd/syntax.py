@@ -26,6 +26,7 @@ SCAL = 0x4C414353  # optional record before a picture: the scaling lists it de-q
 WPRD = 0x44525057  # optional record before a picture: its explicit prediction weights
 TILE = 0x454C4954  # optional record before a picture: (1 + coding-order address, tile index) of every CTU (tiles)
 SLST = 0x54534C53  # optional record before a picture: slice start address of every partition (several slices)
+SLPR = 0x52504C53  # optional record before a picture: its table of per-slice parameters (second header word: entries)
 PCMS = 0x534D4350  # optional record before a picture: PCM sample arrays of the CTUs that hold IPCM units
 _PCM_CTU_BYTES = 4 + (16 + 4 + 4) * abi.PARTS_PER_CTU * 2
 P = abi.PARTS_PER_CTU
@@ -61,6 +62,7 @@ class PictureSyntax:
         self.pred_weights = None  # abi.PredWeights when the picture predicts with explicit weights
         self.slice_start = None  # (nctu, 256) uint32 when the picture has several slices
         self.tiles = None        # (nctu, 2) int32 when the picture has tiles: 1 + coding-order address, tile index
+        self.slices = None       # ctypes array of abi.SliceParams when the slices differ or do not filter across their boundaries
         self.pcm = {}        # ctu address -> (y, cb, cr) int16 arrays, for the CTUs that hold IPCM units
         self.stage_md5 = None  # (3, 3) hex strings: [stage][component]
         self.planes = None   # optional [stage][component] 2-D uint16
@@ -153,7 +155,8 @@ def read_dump(path, max_pictures=None):
             weights = None
             slice_start = None
             tiles = None
-            while tag in (SCAL, PCMS, WPRD, SLST, TILE):
+            slices = None
+            while tag in (SCAL, PCMS, WPRD, SLST, TILE, SLPR):
                 if tag == SCAL:
                     # the 16 bytes just read are the record's tag + 12 bytes of padding
                     scaling = abi.ScalingLists.from_buffer_copy(f.read(C.sizeof(abi.ScalingLists)))
@@ -163,6 +166,8 @@ def read_dump(path, max_pictures=None):
                     slice_start = np.frombuffer(f.read(nctu * P * 4), dtype=np.uint32).reshape(nctu, P).copy()
                 elif tag == TILE:
                     tiles = np.frombuffer(f.read(nctu * 8), dtype=np.int32).reshape(nctu, 2).copy()
+                elif tag == SLPR:
+                    slices = (abi.SliceParams * nctu).from_buffer_copy(f.read(nctu * C.sizeof(abi.SliceParams)))
                 else:
                     for _ in range(nctu):  # second header word: number of CTUs in the record
                         addr = struct.unpack("<i", f.read(4))[0]
@@ -178,6 +183,7 @@ def read_dump(path, max_pictures=None):
             pic.pred_weights = weights
             pic.slice_start = slice_start
             pic.tiles = tiles
+            pic.slices = slices
             raw = f.read(pp_size)
             C.memmove(C.addressof(pic.pic_params), raw, len(raw))
 
@@ -242,6 +248,10 @@ def strip_planes_and_compress(src, dst, preset=6):
             if tag == WPRD:
                 out.write(hdr)
                 out.write(f.read(C.sizeof(abi.PredWeights)))
+                continue
+            if tag == SLPR:
+                out.write(hdr)
+                out.write(f.read(nctu * C.sizeof(abi.SliceParams)))
                 continue
             if tag == PCMS:
                 out.write(hdr)

@@ -56,7 +56,8 @@ typedef struct hevcrecon_seq_params {
   int32_t reserved[6];
 } hevcrecon_seq_params;
 
-/* Picture/slice-level parameters (one slice per picture).
+/* Picture-level parameters, and the slice-level ones of a picture whose slices all agree in them (pictures whose
+ * slices differ add a table with hevcrecon_syntax_set_slices).
  * Sources: TComSlice getters used by TDecCu.cpp:616-625,772-781 (chroma QP offsets),
  * TComLoopFilter.cpp:371,569-570,769 (deblocking), TDecGop.cpp:192-196 (SAO enables),
  * TComSlice::getRefPic / getRefPOC (reference lists). */
@@ -78,8 +79,30 @@ typedef struct hevcrecon_pic_params {
   /* pps->getConstrainedIntraPred(): intra blocks use only neighbours that are themselves intra
    * (TComPattern::is*Available, TLibCommon/TComPattern.cpp:653-830) */
   int32_t constrained_intra_pred;
-  int32_t reserved[7];
+  /* !pps->getLoopFilterAcrossTilesEnabledFlag(): deblocking leaves the edges between tiles alone and SAO treats
+   * them like picture borders (m_bLFCrossTileBoundary, TLibCommon/TComLoopFilter.cpp:383,405,435;
+   * m_bIndependentTileBoundaryForNDBFilter, TLibCommon/TComPic.cpp:170,304-327) */
+  int32_t no_loop_filter_across_tiles;
+  int32_t reserved[6];
 } hevcrecon_pic_params;
+
+/* What the in-loop filters and the chroma de-quantisation read from the slice a CTU belongs to: one entry per slice of
+ * the picture.  Sources: TComLoopFilter.cpp:371-418,569-570,769 (pcCU->getSlice()->getDeblockingFilterDisable /
+ * ...BetaOffsetDiv2 / ...TcOffsetDiv2 / getLFCrossSliceBoundaryFlag), TDecCu.cpp:616-625,772-781 (getSliceQpDeltaCb/Cr),
+ * TDecGop.cpp:151-154 with TComDataCU::setNDBFilterBlockBorderAvailability (TLibCommon/TComDataCU.cpp:3813-4166) for SAO.
+ * Slices end at CTU boundaries (the reference's encoder cannot end them elsewhere).  Slice type, reference lists and
+ * prediction weights are not in the table: the slices of a picture must share them, and the SAO enables are those of
+ * the picture's first slice, which is what the reference applies to the whole picture (TDecGop.cpp:183,194-196). */
+typedef struct hevcrecon_slice_params {
+  uint32_t start_addr;               /* slice->getSliceCurStartCUAddr(): what hevcrecon_ctu_syntax.slice_start holds */
+  int32_t deblocking_disable;
+  int32_t beta_offset_div2;
+  int32_t tc_offset_div2;
+  int32_t cb_qp_delta_slice;
+  int32_t cr_qp_delta_slice;
+  int32_t loop_filter_across_slices; /* slice->getLFCrossSliceBoundaryFlag() */
+  int32_t reserved;
+} hevcrecon_slice_params;
 
 /* One CTU's parsed syntax: plain pointers to the TComDataCU member arrays
  * (TLibCommon/TComDataCU.h:122-204), HEVCRECON_PARTS_PER_CTU entries each, z-order.
@@ -112,14 +135,14 @@ typedef struct hevcrecon_ctu_syntax {
   /* TComDataCU::getSliceStartCU per partition: address (CTU address * 256 + z index) of the first partition of the
    * slice the partition belongs to.  Intra prediction does not use neighbours of other CTUs that lie before it
    * (TComDataCU::getPULeft / getPUAbove / ... with bEnforceSliceRestriction, TLibCommon/TComDataCU.cpp:1141-1589).
-   * NULL: one slice.  The slices of a picture must agree in everything hevcrecon_pic_params carries, and filter
-   * across their boundaries (slice_loop_filter_across_slices_enabled_flag = 1). */
+   * NULL: one slice.  Without a slice table (hevcrecon_syntax_set_slices) the slices of a picture agree in everything
+   * hevcrecon_pic_params carries and filter across their boundaries. */
   const uint32_t *slice_start;
   /* Tiles (TComPicSym::getInverseCUOrderMap / getTileIdxMap, TLibCommon/TComPicSym.h): 1 + the CTU's address in
    * coding order (tile scan), 0 = the same as its raster address; and the index of its tile.  CTUs are always added
    * in coding order.  Intra prediction does not use neighbours of other CTUs that belong to another tile
-   * (bEnforceTileRestriction, TLibCommon/TComDataCU.cpp:1141-1589).  Tiles must filter across their boundaries
-   * (loop_filter_across_tiles_enabled_flag = 1). */
+   * (bEnforceTileRestriction, TLibCommon/TComDataCU.cpp:1141-1589).  Whether the in-loop filters cross tile
+   * boundaries: hevcrecon_pic_params.no_loop_filter_across_tiles. */
   int32_t coding_addr_plus1;
   int32_t tile_id;
 } hevcrecon_ctu_syntax;
@@ -213,6 +236,14 @@ int hevcrecon_syntax_set_scaling_lists(hevcrecon_syntax *syn, const hevcrecon_sc
  * (TComPrediction::xCheckIdenticalMotion, :396-411) is then off for B slices, as in the reference.
  * NULL returns to default prediction.  hevcrecon_syntax_begin resets to default. */
 int hevcrecon_syntax_set_pred_weights(hevcrecon_syntax *syn, const hevcrecon_pred_weights *weights);
+
+/* Optional, after hevcrecon_syntax_begin and before the first hevcrecon_syntax_add_ctu: the picture's slices differ in
+ * the parameters of hevcrecon_slice_params, or do not all filter across their boundaries.  `slices` holds one entry per
+ * slice (any order; copied); every hevcrecon_ctu_syntax.slice_start value of the picture must be the start_addr of one
+ * of them, and all partitions of a CTU must belong to one slice.  With a table, the deblocking parameters and slice
+ * chroma QP deltas of hevcrecon_pic_params are not used.  n = 0 returns to one set of parameters per picture;
+ * hevcrecon_syntax_begin does the same. */
+int hevcrecon_syntax_set_slices(hevcrecon_syntax *syn, int n, const hevcrecon_slice_params *slices);
 
 /* Replaces the call m_pcCuDecoder->decompressCU(pcCU) in TDecSlice::decompressSlice
  * (TLibDecoder/TDecSlice.cpp:367): instead of reconstructing the CTU at once, its syntax

@@ -62,6 +62,7 @@ struct EngineApi {
   int (*syntax_begin)(hevcrecon_syntax *);
   int (*syntax_set_scaling_lists)(hevcrecon_syntax *, const hevcrecon_scaling_lists *);
   int (*syntax_set_pred_weights)(hevcrecon_syntax *, const hevcrecon_pred_weights *);
+  int (*syntax_set_slices)(hevcrecon_syntax *, int, const hevcrecon_slice_params *);
   int (*syntax_add_ctu)(hevcrecon_syntax *, int, const hevcrecon_ctu_syntax *);
   int (*syntax_finish)(hevcrecon_syntax *, const hevcrecon_pic_params *);
   int (*reconstruct)(hevcrecon_ctx *, hevcrecon_syntax *, int);
@@ -113,6 +114,7 @@ struct Bridge {
     sym(api.syntax_begin, "hevcrecon_syntax_begin");
     sym(api.syntax_set_scaling_lists, "hevcrecon_syntax_set_scaling_lists");
     sym(api.syntax_set_pred_weights, "hevcrecon_syntax_set_pred_weights");
+    sym(api.syntax_set_slices, "hevcrecon_syntax_set_slices");
     sym(api.syntax_add_ctu, "hevcrecon_syntax_add_ctu");
     sym(api.syntax_finish, "hevcrecon_syntax_finish");
     sym(api.reconstruct, "hevcrecon_reconstruct");
@@ -157,10 +159,12 @@ struct Bridge {
     pp.cr_qp_offset_pps = sl->getPPS()->getChromaCrQpOffset();
     pp.cb_qp_delta_slice = sl->getSliceQpDeltaCb();
     pp.cr_qp_delta_slice = sl->getSliceQpDeltaCr();
+    // the reference applies the SAO enables of the picture's first slice to the whole picture (TLibDecoder/TDecGop.cpp:183,194-196)
     bool sao = sl->getSPS()->getUseSAO();
-    pp.sao_luma = sao && sl->getSaoEnabledFlag();
-    pp.sao_chroma = sao && sl->getSaoEnabledFlagChroma();
+    pp.sao_luma = sao && pic->getSlice(0)->getSaoEnabledFlag();
+    pp.sao_chroma = sao && pic->getSlice(0)->getSaoEnabledFlagChroma();
     pp.constrained_intra_pred = sl->getPPS()->getConstrainedIntraPred();
+    pp.no_loop_filter_across_tiles = !sl->getPPS()->getLoopFilterAcrossTilesEnabledFlag();
     for (int l = 0; l < 2; l++) {
       pp.num_ref[l] = sl->isIntra() ? 0 : sl->getNumRefIdx(RefPicList(l));
       if (l == 1 && !sl->isInterB()) pp.num_ref[l] = 0;
@@ -210,29 +214,49 @@ struct Bridge {
     return true;
   }
 
-  // Several slices per picture are handed over as one set of picture parameters: they have to agree in everything
-  // those carry, and filter across their boundaries.
+  // What the slices of a picture must share, because it is handed over once per picture: slice type and reference lists.
   void check_slices(TComPic *pic) {
     TComSlice *a = pic->getSlice(pic->getCurrSliceIdx());
     for (UInt i = 0; i < pic->getNumAllocatedSlice() && i <= pic->getCurrSliceIdx(); i++) {
       TComSlice *b = pic->getSlice(i);
-      bool same = a->getSliceType() == b->getSliceType() && a->getDeblockingFilterDisable() == b->getDeblockingFilterDisable() &&
-                  a->getDeblockingFilterBetaOffsetDiv2() == b->getDeblockingFilterBetaOffsetDiv2() &&
-                  a->getDeblockingFilterTcOffsetDiv2() == b->getDeblockingFilterTcOffsetDiv2() &&
-                  a->getSliceQpDeltaCb() == b->getSliceQpDeltaCb() && a->getSliceQpDeltaCr() == b->getSliceQpDeltaCr() &&
-                  a->getSaoEnabledFlag() == b->getSaoEnabledFlag() && a->getSaoEnabledFlagChroma() == b->getSaoEnabledFlagChroma() &&
-                  b->getLFCrossSliceBoundaryFlag();
+      bool same = a->getSliceType() == b->getSliceType();
       for (int l = 0; same && l < 2; l++) {
         same = a->getNumRefIdx(RefPicList(l)) == b->getNumRefIdx(RefPicList(l));
         for (int r = 0; same && !a->isIntra() && r < a->getNumRefIdx(RefPicList(l)); r++)
           same = a->getRefPic(RefPicList(l), r) == b->getRefPic(RefPicList(l), r);
       }
-      same = same && a->getPPS()->getLoopFilterAcrossTilesEnabledFlag();
       if (!same) {
-        fprintf(stderr, "hm_bridge: the slices of POC %d differ in their slice-level parameters or do not filter across slice boundaries\n", a->getPOC());
+        fprintf(stderr, "hm_bridge: the slices of POC %d differ in their type or reference lists\n", a->getPOC());
         exit(EXIT_FAILURE);
       }
     }
+  }
+
+  // The per-slice parameters of the in-loop filters and of the chroma de-quantisation; returns false when the picture
+  // parameters already say everything (one slice, or all slices agree with them and filter across their boundaries).
+  bool fill_slices(TComPic *pic, const hevcrecon_pic_params &pp, std::vector<hevcrecon_slice_params> &out) {
+    out.clear();
+    bool needed = false;
+    for (UInt i = 0; i < pic->getNumAllocatedSlice() && i <= pic->getCurrSliceIdx(); i++) {
+      TComSlice *b = pic->getSlice(i);
+      hevcrecon_slice_params sp;
+      memset(&sp, 0, sizeof(sp));
+      sp.start_addr = b->getSliceCurStartCUAddr();
+      bool seen = false;  // dependent slices repeat their slice's address
+      for (size_t k = 0; k < out.size(); k++) seen = seen || out[k].start_addr == sp.start_addr;
+      if (seen) continue;
+      sp.deblocking_disable = b->getDeblockingFilterDisable();
+      sp.beta_offset_div2 = b->getDeblockingFilterBetaOffsetDiv2();
+      sp.tc_offset_div2 = b->getDeblockingFilterTcOffsetDiv2();
+      sp.cb_qp_delta_slice = b->getSliceQpDeltaCb();
+      sp.cr_qp_delta_slice = b->getSliceQpDeltaCr();
+      sp.loop_filter_across_slices = b->getLFCrossSliceBoundaryFlag();
+      needed = needed || sp.deblocking_disable != pp.deblocking_disable || sp.beta_offset_div2 != pp.beta_offset_div2 ||
+               sp.tc_offset_div2 != pp.tc_offset_div2 || sp.cb_qp_delta_slice != pp.cb_qp_delta_slice ||
+               sp.cr_qp_delta_slice != pp.cr_qp_delta_slice || !sp.loop_filter_across_slices;
+      out.push_back(sp);
+    }
+    return needed && out.size() > 1;
   }
 
   void fill_ctu(TComPic *pic, int addr, const hevcrecon_pic_params &pp, hevcrecon_ctu_syntax &cs, int8_t *refbuf, uint32_t *slicebuf) {
@@ -375,6 +399,12 @@ struct Bridge {
         }
       }
     }
+    std::vector<hevcrecon_slice_params> slices;
+    if (fill_slices(pic, pp, slices)) {  // optional record in front of the picture
+      int32_t lhdr[4] = {0x52504C53 /* "SLPR" */, (int32_t)slices.size(), 0, 0};
+      put(lhdr, 4);
+      put(&slices[0], slices.size());
+    }
     hevcrecon_pred_weights pw;
     if (fill_weights(pic, pw)) {  // optional record in front of the picture
       int32_t whdr[4] = {0x44525057 /* "WPRD" */, 0, 0, 0};
@@ -437,6 +467,8 @@ struct Bridge {
     if (fill_scaling(pic, sl) && api.syntax_set_scaling_lists(syn, &sl)) fail("hevcrecon_syntax_set_scaling_lists");
     hevcrecon_pred_weights pw;
     if (fill_weights(pic, pw) && api.syntax_set_pred_weights(syn, &pw)) fail("hevcrecon_syntax_set_pred_weights");
+    std::vector<hevcrecon_slice_params> slices;
+    if (fill_slices(pic, pp, slices) && api.syntax_set_slices(syn, (int)slices.size(), &slices[0])) fail("hevcrecon_syntax_set_slices");
     int nctu = pic->getNumCUsInFrame();
     for (int i = 0; i < nctu; i++) {
       const int a = (int)pic->getPicSym()->getCUOrderMap(i);  // coding order (tile scan)

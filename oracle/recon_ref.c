@@ -22,6 +22,7 @@
 #define MAXPICS 4096
 #define NPART 256
 #define MAXCTUS 16384 /* 8192 x 8192 luma samples */
+#define MAXSLICES 1024
 
 typedef struct {
   int16_t *p[3];
@@ -42,6 +43,9 @@ typedef struct hevcref_ctx {
   int ctu_order[MAXCTUS];     /* raster address -> position in coding order (tile scan) */
   int use_wp;                 /* predict with the explicit weights below */
   hevcrecon_pred_weights wp;
+  int n_slices;               /* slices differ in their parameters: table below (0: everything from pp) */
+  hevcrecon_slice_params slices[MAXSLICES];
+  const hevcrecon_slice_params *cur_slice; /* slice of the coding unit / CTU being worked on (NULL without a table) */
   int16_t *rec[3];
   uint8_t zscan_x[NPART], zscan_y[NPART]; /* partition z index -> x,y in 4-sample units */
   uint8_t raster_to_z[16][16];             /* [y][x] -> z */
@@ -183,13 +187,26 @@ static PartRef part_at(const hevcref_ctx *c, int x, int y) {
   return r;
 }
 
+/* The table entry of the slice partition z of `ctu` belongs to (pcCU->getSlice() of the reference); NULL when the
+ * picture came without a table. */
+static const hevcrecon_slice_params *slice_of(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int z) {
+  if (!c->n_slices) return NULL;
+  uint32_t start = ctu->slice_start ? ctu->slice_start[z] : 0;
+  for (int i = 0; i < c->n_slices; i++)
+    if (c->slices[i].start_addr == start) return &c->slices[i];
+  return &c->slices[0];
+}
+
 /* ---------------------------------------------------------------- transform -------- */
 
-/* TComTrQuant::setQPforQuant, TLibCommon/TComTrQuant.cpp:192-214 */
+/* TComTrQuant::setQPforQuant, TLibCommon/TComTrQuant.cpp:192-214; the chroma offset is the PPS's plus the slice's
+ * (TLibDecoder/TDecCu.cpp:616-625,772-781) */
 static int scaled_qp(const hevcref_ctx *c, int qpy, int comp) {
   if (comp == 0) return qpy + 6 * (c->sp.bit_depth_luma - 8);
   int bdo = 6 * (c->sp.bit_depth_chroma - 8);
-  int off = comp == 1 ? c->pp->cb_qp_offset_pps + c->pp->cb_qp_delta_slice : c->pp->cr_qp_offset_pps + c->pp->cr_qp_delta_slice;
+  int dcb = c->cur_slice ? c->cur_slice->cb_qp_delta_slice : c->pp->cb_qp_delta_slice;
+  int dcr = c->cur_slice ? c->cur_slice->cr_qp_delta_slice : c->pp->cr_qp_delta_slice;
+  int off = comp == 1 ? c->pp->cb_qp_offset_pps + dcb : c->pp->cr_qp_offset_pps + dcr;
   int q = clip3(-bdo, 57, qpy + off);
   return q < 0 ? q + bdo : kChromaScale[q] + bdo;
 }
@@ -708,6 +725,7 @@ static void decompress_cu(hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int c
     }
     return;
   }
+  c->cur_slice = slice_of(c, ctu, z);
   if (ctu->pred_mode[z] == 1) {
     if (ctu->ipcm && ctu->ipcm[z]) {
       /* TDecCu::xReconPCM / xDecodePCMTexture, TLibDecoder/TDecCu.cpp:798-871: the CU's PCM samples (offset
@@ -811,10 +829,11 @@ static int chroma_qp_deblock(int q) { return q < 0 ? q : (q > 57 ? q - 6 : kChro
  * line = distance between the 4 lines.  keep_p / keep_q: that side belongs to a lossless coding unit and is
  * put back after filtering (bPartPNoFilter / bPartQNoFilter, :633-642,856-867). */
 static void filter_luma_segment(const hevcref_ctx *c, int16_t *s, int step, int line, int bs, int qp, int keep_p, int keep_q) {
-  const hevcrecon_pic_params *pp = c->pp;
   int scale = 1 << (c->sp.bit_depth_luma - 8), maxv = (1 << c->sp.bit_depth_luma) - 1;
-  int tc = kTc[clip3(0, 53, qp + 2 * (bs - 1) + 2 * pp->tc_offset_div2)] * scale;
-  int beta = kBeta[clip3(0, 51, qp + 2 * pp->beta_offset_div2)] * scale;
+  int tc_off = c->cur_slice ? c->cur_slice->tc_offset_div2 : c->pp->tc_offset_div2;
+  int beta_off = c->cur_slice ? c->cur_slice->beta_offset_div2 : c->pp->beta_offset_div2;
+  int tc = kTc[clip3(0, 53, qp + 2 * (bs - 1) + 2 * tc_off)] * scale;
+  int beta = kBeta[clip3(0, 51, qp + 2 * beta_off)] * scale;
   int side = (beta + (beta >> 1)) >> 3, thr_cut = tc * 10;
 #define P(i, k) s[(k) * line - ((i) + 1) * step]
 #define Q(i, k) s[(k) * line + (i) * step]
@@ -861,7 +880,7 @@ static void filter_luma_segment(const hevcref_ctx *c, int16_t *s, int step, int 
 static void filter_chroma_segment(const hevcref_ctx *c, int16_t *s, int step, int line, int qp_avg, int pps_off, int keep_p, int keep_q) {
   int scale = 1 << (c->sp.bit_depth_chroma - 8), maxv = (1 << c->sp.bit_depth_chroma) - 1;
   int qp = chroma_qp_deblock(qp_avg + pps_off);
-  int tc = kTc[clip3(0, 53, qp + 2 + 2 * c->pp->tc_offset_div2)] * scale;
+  int tc = kTc[clip3(0, 53, qp + 2 + 2 * (c->cur_slice ? c->cur_slice->tc_offset_div2 : c->pp->tc_offset_div2))] * scale;
   for (int k = 0; k < 2; k++) {
     int16_t *m = s + k * line;
     int m2 = m[-2 * step], m3 = m[-step], m4 = m[0], m5 = m[step];
@@ -871,9 +890,29 @@ static void filter_chroma_segment(const hevcref_ctx *c, int16_t *s, int step, in
   }
 }
 
+/* TComDataCU::getPULeft / getPUAbove (TLibCommon/TComDataCU.cpp:1141-1238) as the loop filter calls them
+ * (TLibCommon/TComLoopFilter.cpp:383,405): a neighbour inside the same CTU always exists; one in the CTU to the left /
+ * above is dropped when the slice of partition z does not filter across slice boundaries and the neighbour precedes
+ * that slice's start, or when tiles are not crossed and the neighbouring CTU belongs to another tile. */
+static int edge_neighbour_usable(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy, int z, int dir) {
+  int ux = c->zscan_x[z], uy = c->zscan_y[z];
+  if ((dir == 0 ? ux : uy) != 0) return 1;
+  int a = (ctuy >> 6) * c->ctus_w + (ctux >> 6);
+  int na = dir == 0 ? a - 1 : a - c->ctus_w;
+  int nz = dir == 0 ? c->raster_to_z[uy][15] : c->raster_to_z[15][ux];
+  const hevcrecon_slice_params *sl = slice_of(c, ctu, z);
+  if (sl && !sl->loop_filter_across_slices) {
+    uint32_t start = ctu->slice_start ? ctu->slice_start[z] : 0;
+    if ((uint32_t)(c->ctu_order[na] * NPART + nz) < start) return 0;
+  }
+  if (c->pp->no_loop_filter_across_tiles && c->ctus[na].tile_id != ctu->tile_id) return 0;
+  return 1;
+}
+
 /* TComLoopFilter::xDeblockCU for one leaf CU and one direction, TLibCommon/TComLoopFilter.cpp:186-359. */
 static void deblock_cu(hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy, int z, int depth, int dir) {
   int size = 64 >> depth;
+  int skip_cu_edge = 0;
   if (depth < ctu->depth[z]) {
     int np = NPART >> (2 * (depth + 1));
     for (int q = 0; q < 4; q++) {
@@ -883,8 +922,14 @@ static void deblock_cu(hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int ctux
     }
     return;
   }
-  if (ctu->part_size[z] == 15 || c->pp->deblocking_disable) return;
+  if (ctu->part_size[z] == 15) return;
+  /* the parameters are those of the slice the CTU's object points at (pcCU->getSlice(), :371,569-570,769) */
+  c->cur_slice = slice_of(c, ctu, z);
+  if (c->cur_slice ? c->cur_slice->deblocking_disable : c->pp->deblocking_disable) return;
   int x0 = ctux + 4 * c->zscan_x[z], y0 = ctuy + 4 * c->zscan_y[z];
+  /* xSetLoopfilterParam (:363-419): the coding unit's left / top edge is filtered when the neighbour of its first
+   * partition exists for getPULeft / getPUAbove with the slice and tile restrictions the flags ask for */
+  if ((dir == 0 ? x0 : y0) > 0 && !edge_neighbour_usable(c, ctu, ctux, ctuy, z, dir)) skip_cu_edge = 1;
   int tusize = size >> ctu->tr_idx[z]; /* transform edges; refined per partition below */
   (void)tusize;
   int ps = ctu->part_size[z];
@@ -903,6 +948,7 @@ static void deblock_cu(hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int ctux
     for (int u = 0; u < size; u += 4) {  /* 4-sample units along the edge */
       int x = dir == 0 ? x0 + e : x0 + u, y = dir == 0 ? y0 + u : y0 + e;
       if ((dir == 0 ? x : y) == 0) continue; /* picture border */
+      if (e == 0 && skip_cu_edge) continue;
       PartRef q = part_at(c, x, y);
       int tsz = (64 >> q.ctu->depth[q.z]) >> q.ctu->tr_idx[q.z];
       int tu_edge = ((dir == 0 ? x : y) & (tsz - 1)) == 0;
@@ -931,6 +977,34 @@ static inline int sgn(int v) { return (v > 0) - (v < 0); }
  * TLibCommon/TComSampleAdaptiveOffset.cpp:814-1039,1097-1261.  The reference filters in place and
  * keeps line buffers so that every classification sees deblocked samples; reading from an untouched
  * copy (src) is the same thing. */
+/* May SAO classify a sample of CTU `a` against a sample of the CTU (ox, oy) CTUs away?  The neighbouring block exists,
+ * and: same slice, or the later of the two slices filters across its boundaries; and, when tiles are not crossed, no
+ * tile boundary on the sides of `a` that the neighbour lies beyond.  TComDataCU::setNDBFilterBlockBorderAvailability,
+ * TLibCommon/TComDataCU.cpp:3813-4166 (one block per CTU: slices end at CTU boundaries), with the tile sides found
+ * by TComPic::createNonDBFilterInfo, TLibCommon/TComPic.cpp:301-327. */
+static int sao_block_available(const hevcref_ctx *c, int a, int ox, int oy) {
+  int cx = a % c->ctus_w + ox, cy = a / c->ctus_w + oy;
+  if (cx < 0 || cy < 0 || cx >= c->ctus_w || cy >= c->ctus_h) return 0;
+  int n = cy * c->ctus_w + cx;
+  const hevcrecon_ctu_syntax *me = &c->ctus[a], *nb = &c->ctus[n];
+  uint32_t s_me = me->slice_start ? me->slice_start[0] : 0, s_nb = nb->slice_start ? nb->slice_start[0] : 0;
+  if (s_me != s_nb) {
+    const hevcrecon_slice_params *later = s_nb > s_me ? slice_of(c, nb, 0) : slice_of(c, me, 0);
+    if (later && !later->loop_filter_across_slices) return 0;
+  }
+  if (c->pp->no_loop_filter_across_tiles) {
+    if (ox && c->ctus[a + ox].tile_id != me->tile_id) return 0;
+    if (oy && c->ctus[a + oy * c->ctus_w].tile_id != me->tile_id) return 0;
+  }
+  return 1;
+}
+
+/* TComSampleAdaptiveOffset::processSaoUnitAll / processSaoCu (TLibCommon/TComSampleAdaptiveOffset.cpp:546-579,
+ * 1097-1261) with processSaoCuOrg (:814-1039) or, when slices or tiles are not crossed, processSaoBlock (:592-809):
+ * in both a sample is classified only when its two neighbours along the class direction lie in the CTU itself or in a
+ * neighbouring block that may be used (processSaoCuOrg: any block inside the picture).  The reference filters in place
+ * and keeps line buffers / a copy so that every classification sees deblocked samples; reading from an untouched
+ * copy (src) is the same thing. */
 static void sao_ctu(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int comp, int ctux, int ctuy, const int16_t *src,
                     int16_t *dst) {
   int type = ctu->sao_type[comp];
@@ -950,10 +1024,15 @@ static void sao_ctu(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int c
   static const int eo_map[5] = {1, 2, 0, 3, 4};
   int off[5] = {0};
   for (int i = 0; i < 4; i++) off[i + 1] = ctu->sao_offset[comp][i] << inc;
+  int a = (ctuy >> 6) * c->ctus_w + (ctux >> 6);
+  int avail[3][3];
+  for (int oy = -1; oy <= 1; oy++)
+    for (int ox = -1; ox <= 1; ox++) avail[oy + 1][ox + 1] = (ox == 0 && oy == 0) || sao_block_available(c, a, ox, oy);
   for (int y = y0; y < y1; y++)
     for (int x = x0; x < x1; x++) {
       int ax = x - dx[type], ay = y - dy[type], bx = x + dx[type], by = y + dy[type];
-      if (ax < 0 || ay < 0 || bx < 0 || by < 0 || ax >= pw || bx >= pw || ay >= ph || by >= ph) continue;
+      if (!avail[(ay >= y1) - (ay < y0) + 1][(ax >= x1) - (ax < x0) + 1]) continue;
+      if (!avail[(by >= y1) - (by < y0) + 1][(bx >= x1) - (bx < x0) + 1]) continue;
       int v = src[y * pw + x];
       int e = sgn(v - src[ay * pw + ax]) + sgn(v - src[by * pw + bx]) + 2;
       dst[y * pw + x] = (int16_t)clip3(0, maxv, v + off[eo_map[e]]);
@@ -966,6 +1045,14 @@ static void sao_ctu(const hevcref_ctx *c, const hevcrecon_ctu_syntax *ctu, int c
 void hevcref_set_scaling_lists(hevcref_ctx *c, const hevcrecon_scaling_lists *sl) {
   c->use_sl = sl != NULL;
   if (sl) c->sl = *sl;
+}
+
+/* Slice table for the pictures reconstructed from now on (n = 0: one set of parameters per picture). */
+int hevcref_set_slices(hevcref_ctx *c, int n, const hevcrecon_slice_params *sl) {
+  if (n < 0 || n > MAXSLICES) return 1;
+  c->n_slices = n;
+  if (n) memcpy(c->slices, sl, sizeof(*sl) * n);
+  return 0;
 }
 
 /* Explicit prediction weights for the pictures reconstructed from now on (NULL: default prediction). */
@@ -1065,5 +1152,6 @@ int hevcref_upload(hevcref_ctx *c, int pic_id, int poc, const int16_t *y, const 
 void hevcref_inverse_tu(hevcref_ctx *c, const hevcrecon_pic_params *pp, const int32_t *coef, int log2n, int comp, int qpy,
                         int use_dst, int tskip, int16_t *out) {
   c->pp = pp;
+  c->cur_slice = NULL;
   inverse_tu(c, coef, log2n, comp, use_dst, qpy, use_dst, tskip, 0, out);
 }

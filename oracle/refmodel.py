@@ -32,6 +32,7 @@ def _load():
     lib.hevcref_upload.argtypes = [V, C.c_int, C.c_int, V, V, V]
     lib.hevcref_set_scaling_lists.argtypes = [V, V]
     lib.hevcref_set_pred_weights.argtypes = [V, V]
+    lib.hevcref_set_slices.argtypes = [V, C.c_int, V]
     lib.hevcref_inverse_tu.argtypes = [V, C.POINTER(abi.PicParams), V, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, V]
     return lib
 
@@ -56,6 +57,8 @@ class RefModel:
         self.lib.hevcref_set_scaling_lists(self.ctx, C.addressof(sl) if sl is not None else None)
         wp = getattr(pic, "pred_weights", None)
         self.lib.hevcref_set_pred_weights(self.ctx, C.addressof(wp) if wp is not None else None)
+        slices = getattr(pic, "slices", None)
+        self.lib.hevcref_set_slices(self.ctx, len(slices) if slices is not None else 0, C.addressof(slices) if slices is not None else None)
         ctus = pic.ctu_structs()
         rc = self.lib.hevcref_reconstruct(self.ctx, C.byref(pic.pic_params), ctus, pic.nctu, pic.pic_id if dst_id is None else dst_id)
         if rc:

@@ -17,11 +17,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # "bd12": encoder_randomaccess_he10.cfg, 5 frames, --InternalBitDepth=12
 # "slices": encoder_randomaccess_main.cfg, 5 frames of the noise-patch clip, QP 30, --SliceMode=1 --SliceArgument=5
 # "tiles": the same clip and QP, --UniformSpacingIdc=1 --NumTileColumnsMinus1=2 --NumTileRowsMinus1=1 (3 x 2 tiles)
+# "slices_nolf": as "slices" with --LFCrossSliceBoundaryFlag=0; "tiles_nolf": as "tiles" with --LFCrossTileBoundaryFlag=0
+#        (deblocking and SAO stop at slice / tile boundaries)
+# "slices_tiles_nolf": encoder_randomaccess_main.cfg, 9 frames of the plain clip, QP 36, 2 x 2 tiles, slices of 3 CTUs, neither
+#        crossed by the in-loop filters
 # "wpp": encoder_lowdelay_P_main.cfg on a clip that fades to black, -wpP 1 (explicit weights in P slices, 8-bit)
 # "wpb": encoder_randomaccess_he10.cfg on the same clip, -wpP 1 -wpB 1 (explicit weights in B slices, 10-bit)
 STREAMS_240 = ["lowdelay_P_main", "randomaccess_main", "randomaccess_he10", "intra_main", "scalinglist", "lossless", "pcm", "pcmlf",
-               "wpp", "wpb", "cip", "bd12", "slices", "tiles"]
-NUM_PICTURES_240 = {"lossless": 6, "pcm": 5, "pcmlf": 4, "cip": 6, "bd12": 5, "slices": 5, "tiles": 5}  # every other stream has 9
+               "wpp", "wpb", "cip", "bd12", "slices", "tiles", "slices_nolf", "tiles_nolf", "slices_tiles_nolf"]
+NUM_PICTURES_240 = {"lossless": 6, "pcm": 5, "pcmlf": 4, "cip": 6, "bd12": 5, "slices": 5, "tiles": 5, "slices_nolf": 5, "tiles_nolf": 5}  # every other stream has 9
 
 
 def pytest_configure(config):

@@ -20,7 +20,8 @@ def emu_lib():
     return abi.load_library(EMU)
 
 
-@pytest.mark.parametrize("stream,npics", [("randomaccess_he10", 3), ("lowdelay_P_main", 2), ("scalinglist", 2), ("pcm", 1), ("pcmlf", 2), ("wpp", 3), ("wpb", 3), ("cip", 2), ("bd12", 3), ("slices", 2), ("tiles", 2)])
+@pytest.mark.parametrize("stream,npics", [("randomaccess_he10", 3), ("lowdelay_P_main", 2), ("scalinglist", 2), ("pcm", 1), ("pcmlf", 2), ("wpp", 3), ("wpb", 3), ("cip", 2), ("bd12", 3), ("slices", 2), ("tiles", 2),
+                                          ("slices_nolf", 2), ("tiles_nolf", 2), ("slices_tiles_nolf", 2)])
 def test_emulated_engine_matches_oracle(emu_lib, stream, npics):
     seq = load_golden(stream + "_416x240", npics)
     eng = engine.Engine(seq.seq_params, lib=emu_lib)
@@ -296,3 +297,51 @@ def test_emulated_noalloc_entry_point(emu_lib):
     """hevcrecon_reconstruct_noalloc on the emulator: two calls in a row on the one fixed work area (an I picture, then
     a B picture with fewer blocks), each against hevcrecon_reconstruct."""
     _noalloc_matches_regular(emu_lib, ("cip_416x240", 0), ("cip_416x240", 2))
+
+
+def _per_slice_parameters_match_oracle(lib, stream="slices_tiles_nolf", npics=2):
+    """Slices that differ in everything the slice table carries (deblocking on / off, beta and tc offsets, chroma QP
+    deltas, filtering across their boundaries), with an edge-offset SAO class forced on every CTU so that every slice
+    and tile boundary is exercised in all four directions: engine against oracle at all three stages.  (No encoder of
+    the reference writes such a stream; the two sides are independent restatements of the reference's rules.)"""
+    import copy
+
+    seq = load_golden(stream + "_416x240", npics)
+    eng = engine.Engine(seq.seq_params, lib=lib)
+    eng.keep_stages(True)
+    ref = RefModel(seq.seq_params)
+    syn = eng.new_syntax()
+    for n, src in enumerate(seq.pictures):
+        pic = copy.copy(src)
+        pic._keep = None
+        pic.pic_params = type(src.pic_params).from_buffer_copy(src.pic_params)
+        pic.pic_params.sao_luma = pic.pic_params.sao_chroma = 1
+        pic.slices = (abi.SliceParams * len(src.slices)).from_buffer_copy(src.slices)
+        for i, sl in enumerate(pic.slices):
+            sl.deblocking_disable = 1 if i % 4 == 3 else 0
+            sl.beta_offset_div2 = (i * 5) % 13 - 6
+            sl.tc_offset_div2 = (i * 3) % 13 - 6
+            sl.cb_qp_delta_slice = (i * 7) % 25 - 12
+            sl.cr_qp_delta_slice = (i * 11) % 25 - 12
+            sl.loop_filter_across_slices = (i + n) % 2
+        pic.sao = src.sao.copy()
+        for a in range(pic.nctu):
+            for c in range(3):
+                pic.sao[a, c, 0] = (a + c + n) % 5          # all four edge classes and the band class
+                pic.sao[a, c, 1] = (3 * a + c) % 29          # band position
+                pic.sao[a, c, 2:6] = [3, 1, -1, -3] if pic.sao[a, c, 0] < 4 else [5, -4, 3, -2]
+        ref.reconstruct(pic)
+        syn.pack(pic)
+        eng.reconstruct(syn, pic.pic_id)
+        for stage in range(3):
+            got = eng.download(pic.pic_id) if stage == 2 else eng.download_stage(stage)
+            want = ref.download(stage, pic.pic_id)
+            for c in range(3):
+                assert np.array_equal(got[c], want[c]), (pic.poc, stage, c)
+    syn.close()
+    eng.close()
+    ref.close()
+
+
+def test_emulated_per_slice_parameters(emu_lib):
+    _per_slice_parameters_match_oracle(emu_lib)

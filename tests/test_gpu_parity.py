@@ -169,7 +169,7 @@ def test_all_stages_md5_exact_1080p(stream):
     eng.close()
 
 
-@pytest.mark.parametrize("bits,npics", [("lowdelay_P_main_240", 9), ("randomaccess_he10_240", 9), ("scalinglist_240", 9), ("lossless_240", 6), ("pcm_240", 5), ("pcmlf_240", 4), ("wpp_240", 9), ("wpb_240", 9), ("cip_240", 6), ("bd12_240", 5), ("slices_240", 5), ("tiles_240", 5), ("randomaccess_main_1080", 60), ("randomaccess_he10_1080", 60),
+@pytest.mark.parametrize("bits,npics", [("lowdelay_P_main_240", 9), ("randomaccess_he10_240", 9), ("scalinglist_240", 9), ("lossless_240", 6), ("pcm_240", 5), ("pcmlf_240", 4), ("wpp_240", 9), ("wpb_240", 9), ("cip_240", 6), ("bd12_240", 5), ("slices_240", 5), ("tiles_240", 5), ("slices_nolf_240", 5), ("tiles_nolf_240", 5), ("slices_tiles_nolf_240", 9), ("randomaccess_main_1080", 60), ("randomaccess_he10_1080", 60),
                                         # all 60 frames of the all-intra 1080p configuration: the 10.9 MB bitstream is not committed, it lies
                                         # beside the compiled reference (tools/make_fixtures.sh puts it there); its digests are in hm_md5.json
                                         ("oracle/_ref/fixtures/intra_main_1080_f60", 60),
@@ -205,6 +205,14 @@ def test_drop_in_behind_reference_decoder_cli(bits, npics):
         got = [[int(m.group(1)), m.group(2), m.group(3), m.group(4)]
                for m in re.finditer(r"POC\s+(\d+).*?\[MD5:([0-9a-f]{32}),([0-9a-f]{32}),([0-9a-f]{32}),\(OK\)\]", out)]
         assert got == want
+
+
+def test_per_slice_parameters():
+    """Slices with parameters of their own and uncrossed slice / tile boundaries, SAO forced on everywhere."""
+    from test_emulated_kernels import _per_slice_parameters_match_oracle
+    from hevc_amd import abi
+
+    _per_slice_parameters_match_oracle(abi.load_library(), npics=4)
 
 
 @pytest.mark.parametrize("width,height,bit_depth", [(8, 8, 8), (72, 40, 8), (424, 248, 8), (72, 40, 10), (8, 8, 12)])

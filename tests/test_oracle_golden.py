@@ -198,3 +198,24 @@ def test_tile_ids_are_what_makes_the_tiles_stream_match():
     ref.reconstruct(pic)
     luma = ref.download(2, pic.pic_id)[0]
     assert syntax.plane_md5(luma, seq.seq_params.bit_depth_luma) != pic.stage_md5[2][0]
+
+
+@pytest.mark.parametrize("stream", ["slices_nolf", "tiles_nolf", "slices_tiles_nolf"])
+def test_uncrossed_boundaries_are_what_makes_these_streams_match(stream):
+    """Negative control for the streams whose in-loop filters stop at slice / tile boundaries: filtered across them
+    (no slice table, tile flag cleared), the first picture matches before deblocking and must NOT match after."""
+    import copy
+
+    seq = load_golden(stream + "_416x240", 1)
+    pic = copy.copy(seq.pictures[0])
+    assert (pic.slices is not None and any(not s.loop_filter_across_slices for s in pic.slices)) or pic.pic_params.no_loop_filter_across_tiles
+    pic.slices = None
+    pic.pic_params = type(pic.pic_params).from_buffer_copy(pic.pic_params)
+    pic.pic_params.no_loop_filter_across_tiles = 0
+    ref = RefModel(seq.seq_params)
+    ref.reconstruct(pic)
+    bd = seq.seq_params.bit_depth_luma
+    assert syntax.plane_md5(ref.download(0, pic.pic_id)[0], bd) == pic.stage_md5[0][0]
+    assert syntax.plane_md5(ref.download(1, pic.pic_id)[0], bd) != pic.stage_md5[1][0]
+    assert syntax.plane_md5(ref.download(2, pic.pic_id)[0], bd) != pic.stage_md5[2][0]
+    ref.close()

@@ -151,3 +151,44 @@ def test_out_of_range_syntax_is_refused(field, value, what):
     assert lib.hevcrecon_syntax_begin(syn.h) == 0
     assert lib.hevcrecon_syntax_add_ctu(syn.h, 0, C.byref(ctus[0])) == 0
     syn.close()
+
+
+def test_slice_table_is_checked():
+    """hevcrecon_syntax_set_slices: only before the first CTU, values in range, every CTU's slice in the table, and
+    slices that end at CTU boundaries."""
+    seq = load_golden("slices_nolf_416x240", 1)
+    pic = seq.pictures[0]
+    lib = abi.load_library()
+    syn = engine.detached_syntax(seq.seq_params)
+    ctus = pic.ctu_structs()
+    n = len(pic.slices)
+    table = (abi.SliceParams * n).from_buffer_copy(pic.slices)
+    assert lib.hevcrecon_syntax_begin(syn.h) == 0
+    table[1].tc_offset_div2 = 7
+    assert lib.hevcrecon_syntax_set_slices(syn.h, n, C.addressof(table)) != 0
+    assert "out of range" in lib.hevcrecon_syntax_last_error(syn.h).decode()
+    table[1].tc_offset_div2 = 0
+    assert lib.hevcrecon_syntax_set_slices(syn.h, n, C.addressof(table)) == 0  # a refused table does not spoil the picture
+    assert lib.hevcrecon_syntax_add_ctu(syn.h, 0, C.byref(ctus[0])) == 0
+    assert lib.hevcrecon_syntax_set_slices(syn.h, n, C.addressof(table)) != 0  # too late
+    # a table without the second slice: its first CTU (address 5) is refused
+    assert lib.hevcrecon_syntax_begin(syn.h) == 0
+    short = (abi.SliceParams * 1).from_buffer_copy(bytes(table[0]))
+    assert lib.hevcrecon_syntax_set_slices(syn.h, 1, C.addressof(short)) == 0
+    for a in range(5):
+        assert lib.hevcrecon_syntax_add_ctu(syn.h, a, C.byref(ctus[a])) == 0
+    assert lib.hevcrecon_syntax_add_ctu(syn.h, 5, C.byref(ctus[5])) != 0
+    assert "slice table" in lib.hevcrecon_syntax_last_error(syn.h).decode()
+    # a slice that starts inside a CTU
+    assert lib.hevcrecon_syntax_begin(syn.h) == 0
+    assert lib.hevcrecon_syntax_set_slices(syn.h, n, C.addressof(table)) == 0
+    starts = pic.slice_start[0].copy()
+    starts[128:] = table[1].start_addr
+    broken = abi.CtuSyntax.from_buffer_copy(bytes(ctus[0]))
+    broken.slice_start = starts.ctypes.data
+    assert lib.hevcrecon_syntax_add_ctu(syn.h, 0, C.byref(broken)) != 0
+    assert "CTU boundaries" in lib.hevcrecon_syntax_last_error(syn.h).decode()
+    # n = 0 returns to one set of parameters
+    assert lib.hevcrecon_syntax_begin(syn.h) == 0
+    assert lib.hevcrecon_syntax_set_slices(syn.h, 0, None) == 0
+    syn.close()

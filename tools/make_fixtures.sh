@@ -33,6 +33,10 @@ $E -c $cfg/encoder_randomaccess_he10.cfg -i c240.yuv -wdt 416 -hgt 240 -fr 30 -f
 $E -c $cfg/encoder_randomaccess_main.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 5 -q 30 -b slices_240.bin -o /dev/null --SEIpictureDigest=1 --SliceMode=1 --SliceArgument=5 > slices_240.enc.log &
 # 3 x 2 tiles
 $E -c $cfg/encoder_randomaccess_main.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 5 -q 30 -b tiles_240.bin -o /dev/null --SEIpictureDigest=1 --UniformSpacingIdc=1 --NumTileColumnsMinus1=2 --NumTileRowsMinus1=1 > tiles_240.enc.log &
+# the same two with in-loop filters that stop at slice / tile boundaries, and both at once on the plain clip
+$E -c $cfg/encoder_randomaccess_main.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 5 -q 30 -b slices_nolf_240.bin -o /dev/null --SEIpictureDigest=1 --SliceMode=1 --SliceArgument=5 --LFCrossSliceBoundaryFlag=0 > slices_nolf_240.enc.log &
+$E -c $cfg/encoder_randomaccess_main.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 5 -q 30 -b tiles_nolf_240.bin -o /dev/null --SEIpictureDigest=1 --UniformSpacingIdc=1 --NumTileColumnsMinus1=2 --NumTileRowsMinus1=1 --LFCrossTileBoundaryFlag=0 > tiles_nolf_240.enc.log &
+$E -c $cfg/encoder_randomaccess_main.cfg -i c240.yuv -wdt 416 -hgt 240 -fr 30 -f 9 -q 36 -b slices_tiles_nolf_240.bin -o /dev/null --SEIpictureDigest=1 --SliceMode=1 --SliceArgument=3 --LFCrossSliceBoundaryFlag=0 --UniformSpacingIdc=1 --NumTileColumnsMinus1=1 --NumTileRowsMinus1=1 --LFCrossTileBoundaryFlag=0 > slices_tiles_nolf_240.enc.log &
 # IPCM: noise patch at QP 6; 10-bit with 8-bit PCM samples and the in-loop filters off for IPCM units, 8-bit with them on
 $E -c $cfg/encoder_randomaccess_he10.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 5 -q 6 -b pcm_240.bin -o /dev/null --SEIpictureDigest=1 --PCMEnabledFlag=1 --PCMFilterDisableFlag=1 > pcm_240.enc.log &
 $E -c $cfg/encoder_lowdelay_P_main.cfg -i n240.yuv -wdt 416 -hgt 240 -fr 30 -f 4 -q 6 -b pcmlf_240.bin -o /dev/null --SEIpictureDigest=1 --PCMEnabledFlag=1 --PCMFilterDisableFlag=0 > pcmlf_240.enc.log &
@@ -58,7 +62,7 @@ sw lb -c $cfg/encoder_lowdelay_main.cfg -i f240.yuv -f 6 -q 30 &
 wait
 for n in dqp q22 q45 tu lb; do cp sweep_$n.bin "$root/tests/golden/"; done
 D="$root/oracle/_ref/TAppDecoderBridge"
-for s in lowdelay_P_main_240 randomaccess_main_240 randomaccess_he10_240 intra_main_240 scalinglist_240 lossless_240 pcm_240 pcmlf_240 wpp_240 wpb_240 cip_240 bd12_240 slices_240 tiles_240 ra_main_1080 ra_he10_1080 intra_main_1080 intra_main_1080_f60 ra_main_1080_s1 ra_main_1080_s2 ra_main_1080_s3 ra_main_1080_s4 ra_main_1080_s5 ra_main_1080_s6 ra_main_1080_s7; do
+for s in lowdelay_P_main_240 randomaccess_main_240 randomaccess_he10_240 intra_main_240 scalinglist_240 lossless_240 pcm_240 pcmlf_240 wpp_240 wpb_240 cip_240 bd12_240 slices_240 tiles_240 slices_nolf_240 tiles_nolf_240 slices_tiles_nolf_240 ra_main_1080 ra_he10_1080 intra_main_1080 intra_main_1080_f60 ra_main_1080_s1 ra_main_1080_s2 ra_main_1080_s3 ra_main_1080_s4 ra_main_1080_s5 ra_main_1080_s6 ra_main_1080_s7; do
   HEVCRECON_MODE=dump HEVCRECON_DUMP=$s.syn $D -b $s.bin > $s.dec.log
 done
 # the reference decoder's output files at other bit depths than the internal one (digest per frame, display order)
@@ -85,6 +89,7 @@ names = {"lowdelay_P_main_240": "lowdelay_P_main_416x240", "randomaccess_main_24
          "randomaccess_he10_240": "randomaccess_he10_416x240", "intra_main_240": "intra_main_416x240",
          "scalinglist_240": "scalinglist_416x240", "lossless_240": "lossless_416x240",
          "pcm_240": "pcm_416x240", "pcmlf_240": "pcmlf_416x240", "wpp_240": "wpp_416x240", "wpb_240": "wpb_416x240", "cip_240": "cip_416x240", "bd12_240": "bd12_416x240", "slices_240": "slices_416x240", "tiles_240": "tiles_416x240",
+         "slices_nolf_240": "slices_nolf_416x240", "tiles_nolf_240": "tiles_nolf_416x240", "slices_tiles_nolf_240": "slices_tiles_nolf_416x240",
          "ra_main_1080": "randomaccess_main_1920x1080", "ra_he10_1080": "randomaccess_he10_1920x1080",
          "intra_main_1080": "intra_main_1920x1080"}
 names.update({"ra_main_1080_s%d" % k: "randomaccess_main_1920x1080_s%d" % k for k in range(1, 8)})
@@ -101,7 +106,7 @@ for src, dst in names.items():
             rows.append([int(m.group(1)), m.group(2), m.group(3), m.group(4)])
     md5[keys.get(src, src)] = rows
 json.dump(md5, open("tests/golden/hm_md5.json", "w"), indent=0)
-for b in ["lowdelay_P_main_240", "randomaccess_main_240", "randomaccess_he10_240", "intra_main_240", "scalinglist_240", "lossless_240", "pcm_240", "pcmlf_240", "wpp_240", "wpb_240", "cip_240", "bd12_240", "slices_240", "tiles_240"]:
+for b in ["lowdelay_P_main_240", "randomaccess_main_240", "randomaccess_he10_240", "intra_main_240", "scalinglist_240", "lossless_240", "pcm_240", "pcmlf_240", "wpp_240", "wpb_240", "cip_240", "bd12_240", "slices_240", "tiles_240", "slices_nolf_240", "tiles_nolf_240", "slices_tiles_nolf_240"]:
     shutil.copy("work/%s.bin" % b, "tests/golden/%s.bin" % b)
 shutil.copy("work/ra_main_1080.bin", "tests/golden/randomaccess_main_1080.bin")
 shutil.copy("work/ra_he10_1080.bin", "tests/golden/randomaccess_he10_1080.bin")
