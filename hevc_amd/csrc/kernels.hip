@@ -1847,6 +1847,61 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
   }
 }
 
+// Does any lane of the wave that is still in the kernel hold `p`?  (The CPU stand-in's wave vote waits for every lane
+// of the wave, also those that have left the kernel, so there the answer is the safe one.)
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ bool hr_any_lane(bool) { return true; }
+#else
+__device__ __forceinline__ bool hr_any_lane(bool p) { return __any(p) != 0; }
+#endif
+
+// Two 16-bit values per dword (v_pk_* instructions), and byte selection across two dwords (v_perm_b32: selector byte
+// 0-3 picks a byte of lo, 4-7 a byte of hi, 0x0c gives zero).
+#ifdef HEVCRECON_EMULATE
+#define HR_PK2(name, T, expr)                                                          \
+  __device__ __forceinline__ unsigned name(unsigned a, unsigned b) {                   \
+    const T x0 = (T)(a & 0xffffu), x1 = (T)(a >> 16), y0 = (T)(b & 0xffffu), y1 = (T)(b >> 16); \
+    unsigned r0, r1;                                                                   \
+    { const T x = x0, y = y0; r0 = (unsigned)(uint16_t)(expr); }                       \
+    { const T x = x1, y = y1; r1 = (unsigned)(uint16_t)(expr); }                       \
+    return r0 | (r1 << 16);                                                            \
+  }
+HR_PK2(hr_pk_add, uint16_t, x + y)
+HR_PK2(hr_pk_sub, uint16_t, x - y)
+HR_PK2(hr_pk_max_i16, int16_t, x > y ? x : y)
+HR_PK2(hr_pk_min_i16, int16_t, x < y ? x : y)
+HR_PK2(hr_pk_lshr, uint16_t, x >> (y & 15))
+#undef HR_PK2
+__device__ __forceinline__ unsigned hr_perm(unsigned hi, unsigned lo, unsigned sel) {
+  const unsigned long long v = ((unsigned long long)hi << 32) | lo;
+  unsigned r = 0;
+  for (int i = 0; i < 4; i++) {
+    const unsigned c = (sel >> (8 * i)) & 255u;
+    r |= (c < 8 ? (unsigned)((v >> (8 * c)) & 255u) : 0u) << (8 * i);
+  }
+  return r;
+}
+#else
+typedef short hr_i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short hr_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned hr_pk_add(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, (hr_u16x2)(__builtin_bit_cast(hr_u16x2, a) + __builtin_bit_cast(hr_u16x2, b)));
+}
+__device__ __forceinline__ unsigned hr_pk_sub(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, (hr_u16x2)(__builtin_bit_cast(hr_u16x2, a) - __builtin_bit_cast(hr_u16x2, b)));
+}
+__device__ __forceinline__ unsigned hr_pk_max_i16(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(hr_i16x2, a), __builtin_bit_cast(hr_i16x2, b)));
+}
+__device__ __forceinline__ unsigned hr_pk_min_i16(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(hr_i16x2, a), __builtin_bit_cast(hr_i16x2, b)));
+}
+__device__ __forceinline__ unsigned hr_pk_lshr(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, (hr_u16x2)(__builtin_bit_cast(hr_u16x2, a) >> __builtin_bit_cast(hr_u16x2, b)));
+}
+__device__ __forceinline__ unsigned hr_perm(unsigned hi, unsigned lo, unsigned sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // k_sao: sample adaptive offset, deblocked picture -> final picture
 // ------------------------------------------------------------------------------------------------
@@ -1872,19 +1927,21 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
   const int inc = bd > 10 ? bd - 10 : 0;
   // Everything that depends on the CTU's parameters is data, not control flow (the 64 lanes of a wave span 16 CTUs):
   //   edge offset: neighbour a lies towards (-dx,-dy), b towards (+dx,+dy); class = sign(c-a) + sign(c-b) + 2 picks a byte
-  //                of `table` (offsets 0 and 1, zero, offsets 2 and 3); rows at the top / bottom picture border and lanes
-  //                without SAO get an all-zero table, the two samples at the left / right border are put back afterwards
-  //   band offset: band index relative to the first band picks a byte of `table` (the four offsets, then zeros)
+  //                of the table (offsets 0 and 1, zero, offsets 2 and 3); rows at the top / bottom picture border and lanes
+  //                without SAO get a table of zero offsets, the two samples at the left / right border are put back afterwards
+  //   band offset: band index relative to the first band picks a byte of the table (the four offsets, then zero)
+  // Table bytes hold (offset << inc) + 128 (offsets are at most 31 << 2 in magnitude), so that they are unsigned.
   const bool eo = on && sp.type < 4, bo = on && sp.type == 4;
   const int dx = !eo || sp.type == 1 ? 0 : (sp.type == 3 ? -1 : 1), dy = eo && sp.type != 0 ? 1 : 0;
   const bool rows_ok = dy == 0 || (y > 0 && y + 1 < ph);
-  unsigned long long table = 0;
-  if (eo && rows_ok)
-    table = (unsigned long long)(uint8_t)sp.offset[0] | ((unsigned long long)(uint8_t)sp.offset[1] << 8) |
-            ((unsigned long long)(uint8_t)sp.offset[2] << 24) | ((unsigned long long)(uint8_t)sp.offset[3] << 32);
-  if (bo)
-    table = (unsigned long long)(uint8_t)sp.offset[0] | ((unsigned long long)(uint8_t)sp.offset[1] << 8) |
-            ((unsigned long long)(uint8_t)sp.offset[2] << 16) | ((unsigned long long)(uint8_t)sp.offset[3] << 24);
+  auto biased = [&](int k) -> unsigned { return (unsigned)((int)sp.offset[k] * (1 << inc) + 128) & 255u; };
+  const unsigned kNeutral = 0x80808080u;
+  unsigned tlo = kNeutral, thi = kNeutral;
+  if (eo && rows_ok) {
+    tlo = biased(0) | (biased(1) << 8) | (128u << 16) | (biased(2) << 24);
+    thi = biased(3) | 0x80808000u;
+  }
+  if (bo) tlo = biased(0) | (biased(1) << 8) | (biased(2) << 16) | (biased(3) << 24);
   const int dyr = dy && rows_ok ? stride : 0;
   const HR_GLOBAL pel_t *row = src + (size_t)y * stride;
   // A row's samples x-4/B .. x+16+4/B-1 as packed dwords (B = bytes per sample): one dword left of the lane's 16
@@ -1918,29 +1975,15 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
   shifted(wc, 0, pc);
   shifted(wa, -dx, pa);
   shifted(wb, dx, pb);
-  int v[16];
-  const int bsh = bd - 5, band0 = sp.band;
-#pragma unroll
-  for (int i = 0; i < 16; i++) {
-    const int c = sample(pc, i);
-    const int cls = clip3i(-1, 1, c - sample(pa, i)) + clip3i(-1, 1, c - sample(pb, i)) + 2;  // 2 for lanes without edge offset
-    const int idx = bo ? min(((c >> bsh) - band0) & 31, 4) : cls;
-    const int o = (int)(int8_t)(uint8_t)(table >> (8 * idx));
-    v[i] = clip3i(0, maxv, c + (o << inc));
-  }
-  if (dx != 0) {  // picture-border samples of the horizontal and diagonal classes stay as they are
-    if (x == 0) v[0] = sample(pc, 0);
-    if (x + 16 >= pw) {
-#pragma unroll
-      for (int i = 0; i < 16; i++)
-        if (x + i == pw - 1) v[i] = sample(pc, i);
-    }
-  }
+
+  // Slices or tiles that are not filtered across (TComSampleAdaptiveOffset::processSaoBlock,
+  // TLibCommon/TComSampleAdaptiveOffset.cpp:592-809): a sample is classified only when both neighbours along the
+  // class direction lie in its own CTU or in a neighbouring CTU that may be used; the others stay as they are.
+  // Picture borders are unusable neighbours in the same table.  Only the first and the last sample of a CTU's row
+  // can have a neighbour to the side; the others share one answer.
+  bool ok_mid = true, ok_first = true, ok_last = true, at_left = false;
+  int i_last = -1;
   if (J.ctu_info && eo) {
-    // Slices or tiles that are not filtered across (TComSampleAdaptiveOffset::processSaoBlock,
-    // TLibCommon/TComSampleAdaptiveOffset.cpp:592-809): a sample is classified only when both neighbours along the
-    // class direction lie in its own CTU or in a neighbouring CTU that may be used; the others stay as they are.
-    // Picture borders are unusable neighbours in the same table.
     const int cs = comp ? 32 : 64;
     const unsigned am = J.ctu_info[(y >> csh) * s.ctus_w + (x >> csh)].sao_avail;
     auto usable = [&](int ox, int oy) -> bool {
@@ -1950,18 +1993,89 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
     };
     const bool top = (y & (cs - 1)) == 0, bottom = (y & (cs - 1)) == cs - 1 || y == ph - 1;
     const int oy_a = dy && top ? -1 : 0, oy_b = dy && bottom ? 1 : 0;  // neighbour a lies towards (-dx,-dy), b towards (+dx,+dy)
-    const bool ok_mid = usable(0, oy_a) && usable(0, oy_b);
-    const bool at_left = (x & (cs - 1)) == 0;  // the lane's first sample is the first of its CTU's row
-    int i_last = ((x + 16) & (cs - 1)) == 0 ? 15 : -1;  // index of the last sample of the CTU's row, when the lane holds it
+    ok_mid = usable(0, oy_a) && usable(0, oy_b);
+    at_left = (x & (cs - 1)) == 0;                 // the lane's first sample is the first of its CTU's row
+    i_last = ((x + 16) & (cs - 1)) == 0 ? 15 : -1;  // index of the last sample of the CTU's row, when the lane holds it
     if (x + 16 >= pw) i_last = pw - 1 - x;
-    const bool ok_first = usable(dx == 1 ? -1 : 0, oy_a) && usable(dx == -1 ? -1 : 0, oy_b);
-    const bool ok_last = usable(dx == -1 ? 1 : 0, oy_a) && usable(dx == 1 ? 1 : 0, oy_b);
+    ok_first = usable(dx == 1 ? -1 : 0, oy_a) && usable(dx == -1 ? -1 : 0, oy_b);
+    ok_last = usable(dx == -1 ? 1 : 0, oy_a) && usable(dx == 1 ? 1 : 0, oy_b);
+  }
+  const unsigned rlo = tlo, rhi = thi;  // the CTU's own table, for the rare sample that is classified although its row is not
+  if (!ok_mid) tlo = thi = kNeutral;
+
+  // Classification and offset on two samples per dword (16 bits each): 8-bit planes are split into even and odd
+  // samples first.  sign(c - a) + 1 = min(max(c + 1 - a, 0), 2).
+  constexpr int NP = 8;
+  unsigned cp[NP], ap[NP], bp[NP], r[NP];
+  if constexpr (sizeof(pel_t) == 1) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const bool first = i == 0 && at_left, last = i == i_last;
-      // (a CTU row is at least 16 samples long here, so no sample is both)
-      const bool ok = first ? ok_first : (last ? ok_last : ok_mid);
-      if (!ok) v[i] = sample(pc, i);
+    for (int k = 0; k < 4; k++) {
+      cp[2 * k] = hr_perm(0u, pc[k], 0x0c020c00u), cp[2 * k + 1] = hr_perm(0u, pc[k], 0x0c030c01u);
+      ap[2 * k] = hr_perm(0u, pa[k], 0x0c020c00u), ap[2 * k + 1] = hr_perm(0u, pa[k], 0x0c030c01u);
+      bp[2 * k] = hr_perm(0u, pb[k], 0x0c020c00u), bp[2 * k + 1] = hr_perm(0u, pb[k], 0x0c030c01u);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NP; k++) cp[k] = pc[k], ap[k] = pa[k], bp[k] = pb[k];
+  }
+  const unsigned maxvp = (unsigned)maxv * 0x00010001u;
+  const unsigned bshp = (unsigned)(bd - 5) * 0x00010001u, band0p = ((unsigned)sp.band & 0xffffu) * 0x00010001u;
+  const bool any_bo = hr_any_lane(bo);
+#pragma unroll
+  for (int k = 0; k < NP; k++) {
+    const unsigned c1 = hr_pk_add(cp[k], 0x00010001u);
+    const unsigned sa = hr_pk_min_i16(hr_pk_max_i16(hr_pk_sub(c1, ap[k]), 0u), 0x00020002u);
+    const unsigned sb = hr_pk_min_i16(hr_pk_max_i16(hr_pk_sub(c1, bp[k]), 0u), 0x00020002u);
+    unsigned cls = hr_pk_add(sa, sb);
+    if (any_bo) {
+      const unsigned band = hr_pk_min_i16(hr_pk_sub(hr_pk_lshr(cp[k], bshp), band0p) & 0x001f001fu, 0x00040004u);
+      cls = bo ? band : cls;
+    }
+    const unsigned e = hr_perm(thi, tlo, cls | 0x0c000c00u);
+    r[k] = hr_pk_min_i16(hr_pk_max_i16(hr_pk_add(hr_pk_sub(cp[k], 0x00800080u), e), 0u), maxvp);
+  }
+  unsigned out[ND];
+  if constexpr (sizeof(pel_t) == 1) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = hr_perm(r[2 * k + 1], r[2 * k], 0x06020400u);
+  } else {
+#pragma unroll
+    for (int k = 0; k < NP; k++) out[k] = r[k];
+  }
+  // sample i of the result replaced by `val`
+  auto put = [&](int i, int val) {
+    constexpr int BITS = 8 * (int)sizeof(pel_t);
+    const int k = i / SPD, sh = BITS * (i % SPD);
+    out[k] = (out[k] & ~((BITS == 8 ? 0xffu : 0xffffu) << sh)) | ((unsigned)val << sh);
+  };
+  // one sample the plain way, with the CTU's own table
+  auto one = [&](int i) -> int {
+    const int c = sample(pc, i);
+    const int cls = clip3i(-1, 1, c - sample(pa, i)) + clip3i(-1, 1, c - sample(pb, i)) + 2;
+    const int e = (int)(((((unsigned long long)rhi << 32) | rlo) >> (8 * cls)) & 255u);
+    return clip3i(0, maxv, c - 128 + e);
+  };
+  const int i_pic_last = pw - 1 - x;  // index of the picture's last sample of this row, when the lane holds it (< 16)
+  if (dx != 0) {  // picture-border samples of the horizontal and diagonal classes stay as they are
+    if (x == 0) put(0, sample(pc, 0));
+    if (i_pic_last == 15) {
+      put(15, sample(pc, 15));
+    } else if (i_pic_last < 15) {
+#pragma unroll
+      for (int i = 0; i < 15; i++)
+        if (i == i_pic_last) put(i, sample(pc, i));
+    }
+  }
+  if (J.ctu_info && eo && rows_ok) {
+    if (at_left && ok_first != ok_mid) put(0, ok_first ? one(0) : sample(pc, 0));
+    if (i_last >= 0 && ok_last != ok_mid) {
+      if (i_last == 15) {
+        put(15, ok_last ? one(15) : sample(pc, 15));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 15; i++)
+          if (i == i_last) put(i, ok_last ? one(i) : sample(pc, i));
+      }
     }
   }
   if (J.has_bypass) {
@@ -1972,27 +2086,26 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       const int ux = (x + i) >> ush;
-      if (ux < s.uw && (J.rec4[(size_t)uy * s.uw + ux].flags & P4_BYPASS)) v[i] = sample(pc, i);
+      if (ux < s.uw && (J.rec4[(size_t)uy * s.uw + ux].flags & P4_BYPASS)) put(i, sample(pc, i));
     }
   }
   HR_GLOBAL pel_t *orow = dst + (size_t)y * stride + x;
   if constexpr (sizeof(pel_t) == 1) {
     if (x + 16 <= pw) {
-      hr_store16(orow, pack4(v[0], v[1], v[2], v[3]), pack4(v[4], v[5], v[6], v[7]), pack4(v[8], v[9], v[10], v[11]),
-                 pack4(v[12], v[13], v[14], v[15]));
+      hr_store16(orow, out[0], out[1], out[2], out[3]);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        if (x + 4 * q < pw) *(HR_GLOBAL unsigned *)(orow + 4 * q) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        if (x + 4 * q < pw) *(HR_GLOBAL unsigned *)(orow + 4 * q) = out[q];
     }
   } else {
     if (x + 16 <= pw) {
-      hr_store16(orow, pack16(v[0], v[1]), pack16(v[2], v[3]), pack16(v[4], v[5]), pack16(v[6], v[7]));
-      hr_store16(orow + 8, pack16(v[8], v[9]), pack16(v[10], v[11]), pack16(v[12], v[13]), pack16(v[14], v[15]));
+      hr_store16(orow, out[0], out[1], out[2], out[3]);
+      hr_store16(orow + 8, out[4], out[5], out[6], out[7]);
     } else {
 #pragma unroll
       for (int i = 0; i < 16; i++)
-        if (x + i < pw) orow[i] = (pel_t)v[i];
+        if (x + i < pw) orow[i] = (pel_t)sample(out, i);
     }
   }
 }

@@ -200,6 +200,14 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
     }
   }
   for (int c = 0; c < 3; c++) {
+    // what the SAO kernel's offset table holds in a byte: types -1..4, offsets of at most 31 in magnitude (the
+    // syntax allows (1 << (min(bit depth, 10) - 5)) - 1)
+    bool ok = ctu->sao_type[c] >= -1 && ctu->sao_type[c] <= 4;
+    for (int i = 0; i < 4 && ok && ctu->sao_type[c] >= 0; i++) ok = ctu->sao_offset[c][i] >= -31 && ctu->sao_offset[c][i] <= 31;
+    if (!ok) {
+      error = "SAO type or offset out of range";
+      return false;
+    }
     SaoCtu &s = sao[(size_t)addr * 3 + c];
     s.type = (int8_t)ctu->sao_type[c];
     s.band = (int8_t)ctu->sao_subtype[c];

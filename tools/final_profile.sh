@@ -10,14 +10,18 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu-baseline --no-handover --check-two-streams-only > $O/bench_profiled.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --no-cpu-baseline --no-extras --check-two-streams-only > $O/bench_profiled.log 2>&1
+# the same with one context (64 streams): launches that do not share the GPU with another context's kernels
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace1 -- python3 $R/bench.py --no-cpu-baseline --no-extras --check-two-streams-only --streams 64 --contexts 1 > $O/bench_profiled_one_context.log 2>&1
+cp $O/trace1/*/*kernel_stats.csv $O/kernel_stats_one_context.csv
+rm -rf $O/trace1
 cp $O/trace/*/*kernel_stats.csv $O/kernel_stats.csv
 rm -rf $O/trace
 cd $R
 bash tools/pmc_passes.sh 128   # bench defaults: 128 streams over 2 contexts = 64 pictures per launch
 python3 tools/pmc_summary.py gpurun_out/pmc > $O/pmc_summary.txt
-python3 tools/pmc_traffic.py gpurun_out/pmc 64 randomaccess_main_1920x1080 > $O/hbm_traffic.json
+python3 tools/pmc_traffic.py gpurun_out/pmc 64 randomaccess_main_1920x1080 8 > $O/hbm_traffic.json
 rm -rf gpurun_out/pmc/p*/
 cp $O/hbm_traffic.json profiles/hbm_traffic.json  # the bench line below reads its roofline.traffic from there
-timeout -k 10 500 python3 -u bench.py > $O/bench.log 2>&1
+timeout -k 10 900 python3 -u bench.py > $O/bench.log 2>&1
 tail -1 $O/bench.log > $O/bench.json

@@ -3,7 +3,7 @@
 
 Per kernel: HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (both reported in KiB).  The factor 2 is the
 gfx950 correction for wide coalesced reads: FETCH_SIZE tallies 128-byte requests at 64 bytes.
-usage: tools/pmc_traffic.py <pmc dir> <streams> <fixture> > profiles/hbm_traffic.json
+usage: tools/pmc_traffic.py <pmc dir> <pictures per launch> <fixture> <clips> > profiles/hbm_traffic.json
 """
 import collections
 import csv
@@ -12,6 +12,7 @@ import json
 import sys
 
 root, streams, fixture = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+clips = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
 for p in ("p3", "p4"):
@@ -36,7 +37,7 @@ def short_name(k):
     return k.split("<")[0]
 
 
-out = {"streams": streams, "fixture": fixture, "unit": "bytes", "formula": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch", "kernels": {}}
+out = {"streams": streams, "fixture": fixture, "clips": clips, "unit": "bytes", "formula": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch", "kernels": {}}
 for k, v in acc.items():
     if not k.startswith("k_") or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue
