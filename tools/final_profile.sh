@@ -25,3 +25,8 @@ rm -rf gpurun_out/pmc/p*/
 cp $O/hbm_traffic.json profiles/hbm_traffic.json  # the bench line below reads its roofline.traffic from there
 timeout -k 10 900 python3 -u bench.py > $O/bench.log 2>&1
 tail -1 $O/bench.log > $O/bench.json
+# the other 1080p configurations of the reference at the same defaults (one clip each)
+timeout -k 10 600 python3 -u bench.py --fixture randomaccess_he10_1920x1080 --seeds 1 --no-extras --no-cpu-baseline > $O/bench_he10.log 2>&1
+tail -1 $O/bench_he10.log > $O/bench_he10.json
+timeout -k 10 600 python3 -u bench.py --fixture intra_main_1920x1080 --seeds 1 --no-extras --no-cpu-baseline > $O/bench_intra.log 2>&1
+tail -1 $O/bench_intra.log > $O/bench_intra.json
