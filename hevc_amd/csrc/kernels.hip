@@ -383,6 +383,145 @@ __device__ __forceinline__ void interp_u8_filter(const unsigned w[BH + NT - 1][(
     for (int i = 0; i < BW; i++) out[j][i] = acc[j][i] >> 6;
 }
 
+struct __attribute__((packed)) HrBytes16 {
+  unsigned v[4];
+};
+// 16 bytes from any address of a picture plane (one unaligned global_load_dwordx4)
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ void hr_load16(const void *p, unsigned w[4]) {
+  const HrBytes16 q = *(const HrBytes16 *)p;
+  for (int k = 0; k < 4; k++) w[k] = q.v[k];
+}
+__device__ __forceinline__ void hr_store16(void *p, unsigned a, unsigned b, unsigned c, unsigned d) {
+  unsigned *q = (unsigned *)p;
+  q[0] = a, q[1] = b, q[2] = c, q[3] = d;
+}
+#else
+__device__ __forceinline__ void hr_load16(const HR_GLOBAL void *p, unsigned w[4]) {
+  const hr_u32x4 q = *(const HR_GLOBAL hr_u32x4_unaligned *)p;
+  w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+}
+// 16 bytes to a 16-byte aligned address
+__device__ __forceinline__ void hr_store16(HR_GLOBAL void *p, unsigned a, unsigned b, unsigned c, unsigned d) {
+  hr_u32x4 q;
+  q.x = a, q.y = b, q.z = c, q.w = d;
+  *(HR_GLOBAL hr_u32x4 *)p = q;
+}
+#endif
+
+// 2-way 16-bit dot product with 32-bit accumulation (v_dot2_i32_i16)
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ int hr_sdot2(unsigned a, unsigned b, int c) {
+  return c + (int)(int16_t)(a & 0xffff) * (int)(int16_t)(b & 0xffff) + (int)(int16_t)(a >> 16) * (int)(int16_t)(b >> 16);
+}
+#else
+typedef short hr_short2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int hr_sdot2(unsigned a, unsigned b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(hr_short2, a), __builtin_bit_cast(hr_short2, b), c, false);
+}
+#endif
+
+// Packed tap tables (TLibCommon/TComInterpolationFilter.cpp:55-73), read with wave-uniform indices:
+// four signed bytes per dword for the horizontal byte dot products, 16-bit pairs for the vertical ones
+// ("even": taps (0,1)(2,3)...; "odd": the same taps shifted by one row, (-,0)(1,2)...(7,-)).
+#define HR_B4(a, b, c, d) (((unsigned)(a)&255u) | (((unsigned)(b)&255u) << 8) | (((unsigned)(c)&255u) << 16) | (((unsigned)(d)&255u) << 24))
+#define HR_P2(a, b) (((unsigned)(a)&0xffffu) | ((unsigned)(b) << 16))
+#define HR_L8(f, a, b, c, d, e, g, h, i)                                                                 \
+  { HR_B4(a, b, c, d), HR_B4(e, g, h, i), HR_P2(a, b), HR_P2(c, d), HR_P2(e, g), HR_P2(h, i), HR_P2(0, a), HR_P2(b, c), \
+    HR_P2(d, e), HR_P2(g, h), HR_P2(i, 0), 0 }
+#define HR_C4(a, b, c, d) { HR_B4(a, b, c, d), HR_P2(a, b), HR_P2(c, d), HR_P2(0, a), HR_P2(b, c), HR_P2(d, 0), 0, 0 }
+__constant__ unsigned kLumaTab[4][12] = {HR_L8(0, 0, 0, 0, 64, 0, 0, 0, 0), HR_L8(1, -1, 4, -10, 58, 17, -5, 1, 0),
+                                         HR_L8(2, -1, 4, -11, 40, 40, -11, 4, -1), HR_L8(3, 0, 1, -5, 17, 58, -10, 4, -1)};
+__constant__ unsigned kChromaTab[8][8] = {HR_C4(0, 64, 0, 0),    HR_C4(-2, 58, 10, -2), HR_C4(-4, 54, 16, -2), HR_C4(-6, 46, 28, -4),
+                                          HR_C4(-4, 36, 36, -4), HR_C4(-4, 28, 46, -6), HR_C4(-2, 16, 54, -4), HR_C4(-2, 10, 58, -2)};
+
+
+// The same for 16-bit planes: a window row is NW dwords of two samples each, the horizontal filter runs as 2-way
+// 16-bit dot products: an even output uses the tap pairs (0,1)(2,3).., an odd output the pairs shifted by one sample
+// ((-,0)(1,2)..(7,-)), so no sample is ever re-aligned.  pairs[]: the even pairs, then the odd pairs (the layout of
+// kLumaTab[f] + 2 and kChromaTab[f] + 1).
+template <int NT, int BW, int BH>
+__device__ __forceinline__ void interp_u16_load(const HR_GLOBAL uint16_t *ref, int stride, int pw, int ph, int x0, int y0, bool v_identity,
+                                                unsigned w[BH + NT - 1][(BW + NT) / 2]) {
+  constexpr int HALF = NT / 2 - 1;
+  constexpr int NPIX = BW + NT - 1;
+  constexpr int NW = (BW + NT) / 2;
+  constexpr int ROWS = BH + NT - 1;
+  const int xs = x0 - HALF, ys = y0 - HALF;
+  const bool inside = xs >= 0 && xs + 2 * NW - 1 < pw && ys >= 0 && ys + ROWS - 1 < ph;
+  if (inside) {
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      const int rr = v_identity ? clip3i(HALF, HALF + BH - 1, r) : r;
+      const HR_GLOBAL uint16_t *rp = ref + (size_t)(ys + rr) * stride + xs;  // unaligned loads
+      if constexpr (NW == 6) {
+        hr_load16(rp, w[r]);
+        hr_load8(rp + 8, w[r] + 4);
+      } else {
+        hr_load12(rp, w[r]);
+      }
+    }
+  } else {
+    int xb = xs;  // (see tile_row_load: keeps the clamping arithmetic of this rare path inside the branch)
+#ifndef HEVCRECON_EMULATE
+    asm volatile("" : "+v"(xb));
+#endif
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) {
+      const HR_GLOBAL uint16_t *row = ref + (size_t)clip3i(0, ph - 1, ys + r) * stride;
+#pragma unroll
+      for (int k = 0; k < NW; k++) w[r][k] = 0;
+#pragma unroll
+      for (int i = 0; i < NPIX; i++) w[r][i >> 1] |= (unsigned)row[clip3i(0, pw - 1, xb + i)] << (16 * (i & 1));
+    }
+  }
+}
+
+template <int NT, int BW, int BH>
+__device__ __forceinline__ void interp_u16_filter(const unsigned w[BH + NT - 1][(BW + NT) / 2], const unsigned *pairs, const int *cy,
+                                                  bool v_identity, int bd, int out[BH][BW]) {
+  constexpr int HALF = NT / 2 - 1;
+  constexpr int ROWS = BH + NT - 1;
+  constexpr int NE = NT / 2, NO = NT / 2 + 1;  // dot products of an even / odd output
+  const int s1 = bd - 8, init = -(8192 << s1);
+  unsigned te[NE], to[NO];
+#pragma unroll
+  for (int k = 0; k < NE; k++) te[k] = pairs[k];
+#pragma unroll
+  for (int k = 0; k < NO; k++) to[k] = pairs[NE + k];
+  int acc[BH][BW];
+#pragma unroll
+  for (int j = 0; j < BH; j++)
+#pragma unroll
+    for (int i = 0; i < BW; i++) acc[j][i] = 0;
+#pragma unroll
+  for (int r = 0; r < ROWS; r++) {
+    if (v_identity && (r < HALF || r > HALF + BH - 1)) continue;
+#pragma unroll
+    for (int i = 0; i < BW; i++) {
+      const int d = i >> 1;
+      int sum = init;
+      if (i & 1) {
+#pragma unroll
+        for (int k = 0; k < NO; k++) sum = hr_sdot2(w[r][d + k], to[k], sum);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NE; k++) sum = hr_sdot2(w[r][d + k], te[k], sum);
+      }
+      const int h = sum >> s1;
+#pragma unroll
+      for (int j = 0; j < BH; j++) {
+        const int k = r - j;
+        if (k >= 0 && k < NT) acc[j][i] += __mul24(cy[k], h);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < BH; j++)
+#pragma unroll
+    for (int i = 0; i < BW; i++) out[j][i] = acc[j][i] >> 6;
+}
+
 // Final rounding of a prediction, one component: out = clip(((w0*P0 + w1*P1 + add) >> sh) + post), P the 14-bit
 // intermediates (offset by -8192) of the lists in use.
 //   default, one list:  clip((P + 8192 + rnd) >> (14 - bd))                       (TComInterpolationFilter, isLast)
@@ -499,30 +638,35 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
       }
     }
   } else {
+    // 16-bit pictures: one list at a time (a list's windows are 96 registers), its three windows fetched before
+    // anything is filtered
     for (int l = 0; l < 2; l++) {
       if (!(l ? use1 : use0)) continue;
       const int ri = p.ref_idx[l];
       const int mvx = min(hmax, max(hmin, (int)p.mv[l][0])), mvy = min(vmax, max(vmin, (int)p.mv[l][1]));
+      unsigned wy[11][6], wc[2][5][3];
+      interp_u16_load<8, 4, 4>((const HR_GLOBAL uint16_t *)J.ref[l][ri][0], s.stride_y, s.w, s.h, x + (mvx >> 2), y + (mvy >> 2),
+                               (mvy & 3) == 0, wy);
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+        interp_u16_load<4, 2, 2>((const HR_GLOBAL uint16_t *)J.ref[l][ri][1 + c], s.stride_c, s.cw, s.ch, (x >> 1) + (mvx >> 3),
+                                 (y >> 1) + (mvy >> 3), (mvy & 7) == 0, wc[c]);
       {
-        int tx[8], ty[8], o[4][4];
-        luma_taps(mvx & 3, tx);
+        int ty[8], o[4][4];
         luma_taps(mvy & 3, ty);
-        interp_block<pel_t, 8, 4, 4>(plane_c<pel_t>(J.ref[l][ri][0]), s.stride_y, s.w, s.h, x + (mvx >> 2), y + (mvy >> 2), tx, ty,
-                                     s.bd_y, o);
+        interp_u16_filter<8, 4, 4>(wy, kLumaTab[mvx & 3] + 2, ty, (mvy & 3) == 0, s.bd_y, o);
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
           for (int i = 0; i < 4; i++) ly[j][i] += WP ? __mul24(Ry.w[l], o[j][i]) : o[j][i];
       }
       {
-        int tx[4], ty[4];
-        chroma_taps(mvx & 7, tx);
+        int ty[4];
         chroma_taps(mvy & 7, ty);
 #pragma unroll
         for (int c = 0; c < 2; c++) {
           int o[2][2];
-          interp_block<pel_t, 4, 2, 2>(plane_c<pel_t>(J.ref[l][ri][1 + c]), s.stride_c, s.cw, s.ch, (x >> 1) + (mvx >> 3),
-                                       (y >> 1) + (mvy >> 3), tx, ty, s.bd_c, o);
+          interp_u16_filter<4, 2, 2>(wc[c], kChromaTab[mvx & 7] + 1, ty, (mvy & 7) == 0, s.bd_c, o);
 #pragma unroll
           for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -590,16 +734,6 @@ __global__ __launch_bounds__(256) void k_inter_blk(const PicJob *jobs, SeqInfo s
 //   store    the tile is written out as dwords.
 // Arithmetic as in interp_u8: samples biased by 128 so the horizontal sums ARE the reference's 14-bit
 // intermediates; TComInterpolationFilter.cpp:165-246, TComPrediction.cpp:413-507, TComYuv.cpp:520-584.
-#ifdef HEVCRECON_EMULATE
-__device__ __forceinline__ int hr_sdot2(unsigned a, unsigned b, int c) {
-  return c + (int)(int16_t)(a & 0xffff) * (int)(int16_t)(b & 0xffff) + (int)(int16_t)(a >> 16) * (int)(int16_t)(b >> 16);
-}
-#else
-typedef short hr_short2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int hr_sdot2(unsigned a, unsigned b, int c) {
-  return __builtin_amdgcn_sdot2(__builtin_bit_cast(hr_short2, a), __builtin_bit_cast(hr_short2, b), c, false);
-}
-#endif
 // Final rounding of the tile kernels: clip((v + off) >> sh) to a byte.  The shifted value is hidden from the
 // optimiser on purpose: hipcc (ROCm 7.2) otherwise fuses "shift, clamp to 0..255, pack two bytes" into
 // v_ashr_pk_u8_i32 and then ORs the other two bytes into the upper half of its result register, which that
@@ -616,32 +750,6 @@ __device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)l
 #else
 // low halves of two registers in one instruction (v_perm_b32: bytes 0,1 of lo, then bytes 0,1 of hi)
 __device__ __forceinline__ unsigned pack16(int lo, int hi) { return __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
-#endif
-
-struct __attribute__((packed)) HrBytes16 {
-  unsigned v[4];
-};
-// 16 bytes from any address of a picture plane (one unaligned global_load_dwordx4)
-#ifdef HEVCRECON_EMULATE
-__device__ __forceinline__ void hr_load16(const void *p, unsigned w[4]) {
-  const HrBytes16 q = *(const HrBytes16 *)p;
-  for (int k = 0; k < 4; k++) w[k] = q.v[k];
-}
-__device__ __forceinline__ void hr_store16(void *p, unsigned a, unsigned b, unsigned c, unsigned d) {
-  unsigned *q = (unsigned *)p;
-  q[0] = a, q[1] = b, q[2] = c, q[3] = d;
-}
-#else
-__device__ __forceinline__ void hr_load16(const HR_GLOBAL void *p, unsigned w[4]) {
-  const hr_u32x4 q = *(const HR_GLOBAL hr_u32x4_unaligned *)p;
-  w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
-}
-// 16 bytes to a 16-byte aligned address
-__device__ __forceinline__ void hr_store16(HR_GLOBAL void *p, unsigned a, unsigned b, unsigned c, unsigned d) {
-  hr_u32x4 q;
-  q.x = a, q.y = b, q.z = c, q.w = d;
-  *(HR_GLOBAL hr_u32x4 *)p = q;
-}
 #endif
 
 // 16 bytes of a picture row starting at sample x0; without `fast` every sample position is clamped into the row
@@ -678,20 +786,6 @@ __device__ __forceinline__ void tile_row_load(const HR_GLOBAL uint16_t *row, int
     for (int i = 0; i < 16; i++) w[i >> 1] |= (unsigned)row[clip3i(0, pw - 1, xb + i)] << (16 * (i & 1));
   }
 }
-
-// Packed tap tables (TLibCommon/TComInterpolationFilter.cpp:55-73), read with wave-uniform indices:
-// four signed bytes per dword for the horizontal byte dot products, 16-bit pairs for the vertical ones
-// ("even": taps (0,1)(2,3)...; "odd": the same taps shifted by one row, (-,0)(1,2)...(7,-)).
-#define HR_B4(a, b, c, d) (((unsigned)(a)&255u) | (((unsigned)(b)&255u) << 8) | (((unsigned)(c)&255u) << 16) | (((unsigned)(d)&255u) << 24))
-#define HR_P2(a, b) (((unsigned)(a)&0xffffu) | ((unsigned)(b) << 16))
-#define HR_L8(f, a, b, c, d, e, g, h, i)                                                                 \
-  { HR_B4(a, b, c, d), HR_B4(e, g, h, i), HR_P2(a, b), HR_P2(c, d), HR_P2(e, g), HR_P2(h, i), HR_P2(0, a), HR_P2(b, c), \
-    HR_P2(d, e), HR_P2(g, h), HR_P2(i, 0), 0 }
-#define HR_C4(a, b, c, d) { HR_B4(a, b, c, d), HR_P2(a, b), HR_P2(c, d), HR_P2(0, a), HR_P2(b, c), HR_P2(d, 0), 0, 0 }
-__constant__ unsigned kLumaTab[4][12] = {HR_L8(0, 0, 0, 0, 64, 0, 0, 0, 0), HR_L8(1, -1, 4, -10, 58, 17, -5, 1, 0),
-                                         HR_L8(2, -1, 4, -11, 40, 40, -11, 4, -1), HR_L8(3, 0, 1, -5, 17, 58, -10, 4, -1)};
-__constant__ unsigned kChromaTab[8][8] = {HR_C4(0, 64, 0, 0),    HR_C4(-2, 58, 10, -2), HR_C4(-4, 54, 16, -2), HR_C4(-6, 46, 28, -4),
-                                          HR_C4(-4, 36, 36, -4), HR_C4(-4, 28, 46, -6), HR_C4(-2, 16, 54, -4), HR_C4(-2, 10, 58, -2)};
 
 // first product of a dot-product chain.  (Not inline assembly with a literal zero accumulator: results of
 // the dot instructions need wait states before another VALU instruction reads them on this hardware, which the
