@@ -472,6 +472,20 @@ def main():
                         engs[0].reconstruct_prepared(p)
                 engs[0].synchronize()
                 side["streams_%d_frames_per_s" % n_small] = round(2 * npic * n_small / (time.perf_counter() - t0), 1)
+        if C >= 2 and len(groups[0]) >= 4 and len(groups[1]) >= 4:
+            # the same 8 streams as two contexts of 4, half a pass apart: one context's launch latency and intra chain
+            # run beside the other's kernels
+            subs = [groups[0][:4], groups[1][:4]]
+            preps = [[engs[c].prepare_batch([W.syns[t][s] for s in subs[c]], [W.pic_id(s, t) for s in subs[c]]) for t in range(npic)] for c in range(2)]
+            for rep in range(3):
+                if rep == 1:
+                    sync()
+                    t0 = time.perf_counter()
+                for t in range(npic):
+                    engs[0].reconstruct_prepared(preps[0][t])
+                    engs[1].reconstruct_prepared(preps[1][(t + npic // 2) % npic])
+            sync()
+            side["streams_8_over_two_contexts_frames_per_s"] = round(2 * npic * 8 / (time.perf_counter() - t0), 1)
         if not args.stagger and S >= 2 * C:
             W.set_offsets(True)
             gg = 0

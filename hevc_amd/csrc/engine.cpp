@@ -865,7 +865,7 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
   const SeqInfo &s = c->si;
   PicJob *jh = ws.jobs_host, *jd = ws.jobs_dev;
   if (c->ring_used[ws.slot]) HIPCHK(c, hipEventSynchronize(c->ring_ev[ws.slot]));
-  int max_tu[4] = {0, 0, 0, 0}, max_levels = 0, max_mct[3] = {0, 0, 0}, max_mcb = 0;
+  int max_tu[4] = {0, 0, 0, 0}, max_small_groups = 0, max_levels = 0, max_mct[3] = {0, 0, 0}, max_mcb = 0;
   bool any_deblock = false, any_sao = false, any_wp = false, any_expand = false;
   for (int i = 0; i < n; i++) {
     hevcrecon_syntax *y = syn[i];
@@ -905,6 +905,8 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
       j.n_tu[t] = (int)k.tu[t].size();
       if (j.n_tu[t] > max_tu[t]) max_tu[t] = j.n_tu[t];
     }
+    // workgroups of the launch that the 16x16, 8x8 and 4x4 blocks share (16, 32 and 64 blocks per workgroup)
+    max_small_groups = std::max(max_small_groups, (j.n_tu[2] + 15) / 16 + (j.n_tu[1] + 31) / 32 + (j.n_tu[0] + 63) / 64);
     j.coeff = (const uint32_t *)(y->up_dev + y->off_coeff);
     for (int p = 0; p < 3; p++) j.resi[p] = (int16_t *)((char *)ws.resi_base[i] + c->resi_off[p]);
     j.intra = (const IntraItem *)(y->up_dev + y->off_intra);
@@ -1038,12 +1040,12 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
     }
   }
   {
-    int nl = 0;
-    for (int t = 0; t < 4; t++) nl += max_tu[t] > 0;
+    // the 32x32 blocks in one launch, all smaller blocks in another
+    const int nl = (max_tu[3] > 0) + (max_small_groups > 0);
     if (nl) {
       Timed tm(c, K_TRANSFORM, nl, !ws.fixed);
-      for (int t = 0; t < 4; t++)
-        if (max_tu[t] > 0) hr_launch(K_TRANSFORM, jd, n, s, c->stream, t + 2, max_tu[t]);
+      if (max_tu[3] > 0) hr_launch(K_TRANSFORM, jd, n, s, c->stream, 5, max_tu[3]);
+      if (max_small_groups > 0) hr_launch(K_TRANSFORM, jd, n, s, c->stream, 0, max_small_groups);
     }
   }
   if (n_intra_ctus > 0) {

@@ -196,7 +196,7 @@ __device__ __forceinline__ void chroma_taps(int frac, int c[4]) {
   }
 }
 
-// Separable interpolation of a BW x BH block with NT taps, producing the 14-bit intermediate of the
+// Separable interpolation of a BW x BH block with NT taps produces the 14-bit intermediate of the
 // reference's bi-prediction path: horizontal pass (sum - (8192 << s1)) >> s1, s1 = bd - 8, then the
 // vertical pass sum >> 6 (TLibCommon/TComInterpolationFilter.cpp:165-246 with isLast = false).
 // Running a zero fraction through the identity filter {..64..} reproduces the reference's shortcut
@@ -204,43 +204,6 @@ __device__ __forceinline__ void chroma_taps(int frac, int c[4]) {
 // the same intermediate: clip((v + 8192 + (1 << (13 - bd))) >> (14 - bd)).
 // Reference samples outside the picture are read with clamped coordinates, which equals the
 // reference's replicated 80-sample border because clipped vectors never reach beyond it.
-template <typename pel_t, int NT, int BW, int BH>
-__device__ __forceinline__ void interp_block(const pel_t *ref, int stride, int pw, int ph, int x0, int y0, const int *cx,
-                                             const int *cy, int bd, int out[BH][BW]) {
-  const int s1 = bd - 8;
-  const int off1 = 8192 << s1;
-  int xo[BW + NT - 1];
-#pragma unroll
-  for (int i = 0; i < BW + NT - 1; i++) xo[i] = clip3i(0, pw - 1, x0 + i - (NT / 2 - 1));
-  int acc[BH][BW];
-#pragma unroll
-  for (int j = 0; j < BH; j++)
-#pragma unroll
-    for (int i = 0; i < BW; i++) acc[j][i] = 0;
-#pragma unroll
-  for (int r = 0; r < BH + NT - 1; r++) {
-    const pel_t *row = ref + (size_t)clip3i(0, ph - 1, y0 + r - (NT / 2 - 1)) * stride;
-    int px[BW + NT - 1];
-#pragma unroll
-    for (int i = 0; i < BW + NT - 1; i++) px[i] = row[xo[i]];
-#pragma unroll
-    for (int i = 0; i < BW; i++) {
-      int sum = 0;
-#pragma unroll
-      for (int k = 0; k < NT; k++) sum += cx[k] * px[i + k];
-      int h = (sum - off1) >> s1;  // 16-bit intermediate of the reference
-#pragma unroll
-      for (int j = 0; j < BH; j++) {
-        const int k = r - j;  // tap index of this row for output row j
-        if (k >= 0 && k < NT) acc[j][i] += cy[k] * h;
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < BH; j++)
-#pragma unroll
-    for (int i = 0; i < BW; i++) out[j][i] = acc[j][i] >> 6;
-}
 
 // ---- byte-packed fast path for 8-bit pictures -------------------------------------------------------
 #ifdef HEVCRECON_EMULATE
@@ -259,7 +222,7 @@ __device__ __forceinline__ unsigned pack4(int a, int b, int c, int d) {
   return (unsigned)(a & 255) | ((unsigned)(b & 255) << 8) | ((unsigned)(c & 255) << 16) | ((unsigned)(d & 255) << 24);
 }
 
-// Same arithmetic as interp_block for 8-bit samples, organised for the hardware: a row of the reference
+// That arithmetic for 8-bit samples, organised for the hardware: a row of the reference
 // window is fetched as aligned dwords and shifted into place (v_alignbyte), samples are biased to signed
 // bytes (x ^ 0x80 = x - 128) and the horizontal filter is two 4-way byte dot products.  Because the taps sum
 // to 64, sum(c_k * (p_k - 128)) = sum(c_k * p_k) - 8192, which IS the reference's 14-bit intermediate at
@@ -343,7 +306,7 @@ __device__ __forceinline__ void interp_u8_load(const HR_GLOBAL uint8_t *ref, int
   }
 }
 
-// Same arithmetic as interp_block for 8-bit samples, organised for the hardware: samples biased to signed
+// The arithmetic above for 8-bit samples, organised for the hardware: samples biased to signed
 // bytes (x ^ 0x80 = x - 128), the horizontal filter is two 4-way byte dot products.  Because the taps sum
 // to 64, sum(c_k * (p_k - 128)) = sum(c_k * p_k) - 8192, which IS the reference's 14-bit intermediate at
 // bit depth 8 (offset 8192, shift 0).  Rows whose vertical tap is zero are skipped when the vertical
@@ -1086,14 +1049,14 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
 // coefficient row that is zero in the whole wave is skipped.
 // De-quantisation: TComTrQuant::xDeQuant flat path (TLibCommon/TComTrQuant.cpp:1174-1185) with the QP of
 // TComTrQuant::setQPforQuant (:192-214); transform skip: xITransformSkip (:1454-1486).
+// `group`: which 256 / N transform blocks of the picture's list of this size the workgroup takes; `lds`: TPB * N * (N + 1) words.
 template <typename pel_t, int LOG2N>
-__global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s) {
+__device__ __forceinline__ void transform_blocks(const PicJob &J, const SeqInfo &s, int group, int *lds) {
   constexpr int N = 1 << LOG2N;
   constexpr int TPB = 256 / N;  // transform blocks per workgroup
-  __shared__ int tmp[TPB][N][N + 1];
-  const PicJob &J = jobs[blockIdx.y];
+  int(*tmp)[N][N + 1] = (int(*)[N][N + 1])lds;
   const int t_local = threadIdx.x / N, c = threadIdx.x % N;
-  const int t_idx = blockIdx.x * TPB + t_local;
+  const int t_idx = group * TPB + t_local;
   const bool live = t_idx < J.n_tu[LOG2N - 2];
   TuItem it;
   it.x = it.y = 0;
@@ -1335,6 +1298,29 @@ tile0[py * tw + px] = (uint16_t)clip3i(0, maxv, v);              \
 #undef EE
     }
 #undef INTRA_STORE_LOOP
+}
+
+// The 32x32 blocks have a launch of their own (33 KB of LDS and 103 registers per lane would cost the small blocks
+// their occupancy); the 16x16, 8x8 and 4x4 blocks of a picture share one: its workgroups take the 16x16 groups first.
+template <typename pel_t, int LOG2N>
+__global__ __launch_bounds__(256) void k_transform(const PicJob *jobs, SeqInfo s) {
+  constexpr int N = 1 << LOG2N;
+  __shared__ int lds[(256 / N) * N * (N + 1)];
+  transform_blocks<pel_t, LOG2N>(jobs[blockIdx.y], s, blockIdx.x, lds);
+}
+
+template <typename pel_t>
+__global__ __launch_bounds__(256) void k_transform_small(const PicJob *jobs, SeqInfo s) {
+  __shared__ int lds[16 * 16 * 17];  // the largest of 16 x (16 x 17), 32 x (8 x 9), 64 x (4 x 5)
+  const PicJob &J = jobs[blockIdx.y];
+  const int g16 = (J.n_tu[2] + 15) >> 4, g8 = (J.n_tu[1] + 31) >> 5, g4 = (J.n_tu[0] + 63) >> 6;
+  const int b = blockIdx.x;
+  if (b < g16)
+    transform_blocks<pel_t, 4>(J, s, b, lds);
+  else if (b < g16 + g8)
+    transform_blocks<pel_t, 3>(J, s, b - g16, lds);
+  else if (b < g16 + g8 + g4)
+    transform_blocks<pel_t, 2>(J, s, b - g16 - g8, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2349,13 +2335,10 @@ static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, 
       if (arg == 7) LAUNCH((k_inter_blk<pel_t, true>), dim3((arg2 + 15) / 16, n), dim3(256), st, jobs, s);
       break;
     case K_TRANSFORM: {
-      // arg = log2 size, arg2 = max number of blocks of that size over the batch
-      const int tpb = 256 >> arg;
-      const dim3 g((arg2 + tpb - 1) / tpb, n);
-      if (arg == 2) LAUNCH((k_transform<pel_t, 2>), g, dim3(256), st, jobs, s);
-      if (arg == 3) LAUNCH((k_transform<pel_t, 3>), g, dim3(256), st, jobs, s);
-      if (arg == 4) LAUNCH((k_transform<pel_t, 4>), g, dim3(256), st, jobs, s);
-      if (arg == 5) LAUNCH((k_transform<pel_t, 5>), g, dim3(256), st, jobs, s);
+      // arg = 5: the 32x32 blocks, arg2 = their largest count over the batch; arg = 0: the smaller blocks, arg2 = the
+      // largest number of workgroups a picture of the batch needs for them
+      if (arg == 5) LAUNCH((k_transform<pel_t, 5>), dim3((arg2 + 7) / 8, n), dim3(256), st, jobs, s);
+      if (arg == 0) LAUNCH((k_transform_small<pel_t>), dim3(arg2, n), dim3(256), st, jobs, s);
       break;
     }
     case K_OTHER:
