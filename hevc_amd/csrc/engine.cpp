@@ -413,6 +413,9 @@ int download_planes(hevcrecon_ctx *c, const DevPicture &p, int16_t *y, int16_t *
 void destroy_context(hevcrecon_ctx *c) {
   hipSetDevice(c->device);
   if (std::getenv("HEVCRECON_DEBUG")) std::fprintf(stderr, "hevcrecon: longest wait of an intra CTU for a neighbour: %d polls\n", c->longest_intra_wait);
+#ifdef HEVCRECON_INTRA_STAMPS
+  hr_intra_stamps_report();
+#endif
   // nothing may still be using the buffers freed below: the kernels' stream first, then the copy streams the
   // contexts of this device share (they read the pinned upload ring and write its device mirror)
   if (c->stream) hipStreamSynchronize(c->stream);

@@ -27,4 +27,8 @@ void hr_launch_output(const void *const planes[3], void *dst, const SeqInfo &s, 
 // hash is a serial chain, so this only pays with many planes in flight.
 void hr_launch_md5(const Md5Plane *planes, int n, uint8_t *digests, hipStream_t stream);
 
+#ifdef HEVCRECON_INTRA_STAMPS
+void hr_intra_stamps_report();
+#endif
+
 #endif

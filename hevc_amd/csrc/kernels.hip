@@ -103,7 +103,7 @@ __device__ __forceinline__ void hr_acquire() {
 }
 // constant 100 MHz clock, for bounding waits by time rather than by iterations
 __device__ __forceinline__ unsigned long long hr_clock100() { return __builtin_amdgcn_s_memrealtime(); }
-__device__ __forceinline__ void hr_nap() { __builtin_amdgcn_s_sleep(32); }  // ~1 us between polls: waits last tens of them
+__device__ __forceinline__ void hr_nap() { __builtin_amdgcn_s_sleep(4); }  // ~0.1 us between polls: a CTU on the critical chain starts that soon after its neighbour
 #endif
 
 // Core transform matrix of the 32-point inverse DCT: entry (k, i) is round(64*sqrt(2)*cos(pi*k*(2i+1)/64)) as
@@ -1339,6 +1339,26 @@ __global__ __launch_bounds__(256) void k_transform_small(const PicJob *jobs, Seq
 #define IT_MAX_ITEMS HR_INTRA_MAX_ITEMS
 #define IT_MAX_LEVELS HR_INTRA_MAX_LEVELS
 
+// Diagnostic build only (-DHEVCRECON_INTRA_STAMPS): cycles that lane 0 of every workgroup spends in each phase of a
+// CTU, summed over the launch; read back and printed by hr_intra_stamps_report().
+#ifdef HEVCRECON_INTRA_STAMPS
+__device__ unsigned long long hr_intra_stamps[8];
+#define HR_STAMP(k)                                                                   \
+  if (tid == 0) {                                                                     \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                     \
+    atomicAdd(&hr_intra_stamps[k], now_ - stamp_);                                    \
+    stamp_ = now_;                                                                    \
+  }
+void hr_intra_stamps_report() {
+  unsigned long long v[8];
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(hr_intra_stamps), sizeof v) != hipSuccess) return;
+  const char *names[8] = {"ticket", "wait for neighbours", "staging", "rounds", "write-back issue", "drain + barrier", "CTUs", ""};
+  for (int k = 0; k < 7; k++) fprintf(stderr, "k_intra %-20s %llu\n", names[k], v[k]);
+}
+#else
+#define HR_STAMP(k)
+#endif
+
 template <typename pel_t>
 __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s, const unsigned *list, int n_items, unsigned *ticket) {
   __shared__ uint16_t tile_y[65 * IT_YW];
@@ -1356,16 +1376,37 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
   // picture the order of its own table, list = NULL).  Workgroups draw the next entry until the list is exhausted
   // and wait, per CTU, for the neighbouring CTUs it depends on.  Whatever the number of workgroups resident at a
   // time, the earliest unfinished entry never waits for an entry that has not been drawn, so the launch drains.
+#ifdef HEVCRECON_INTRA_STAMPS
+  unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
   for (;;) {
   __syncthreads();  // the previous CTU's tile has been written back by every wave
   if (tid == 0) ticket_s = hr_ticket_take(ticket);
   __syncthreads();
   const unsigned entry_idx = ticket_s;
   if (entry_idx >= (unsigned)n_items) break;
+  HR_STAMP(0)
   const unsigned entry = list ? list[entry_idx] : entry_idx;
   const PicJob &J = jobs[entry >> 16];
   const IntraCtu ci = J.ictu[entry & 0xffffu];
   const int ctux = ci.cx * 64, ctuy = ci.cy * 64;
+  // What the CTU needs that no neighbouring CTU produces -- its residual, its block list -- is requested now and
+  // lands in registers while lane 0 waits for the neighbours: one item of each kind per lane.
+  const int nit = ci.n_items < IT_MAX_ITEMS ? ci.n_items : IT_MAX_ITEMS;
+  uint4 pre_ry = make_uint4(0, 0, 0, 0), pre_item = make_uint4(0, 0, 0, 0);
+  uint2 pre_rc = make_uint2(0, 0);
+  unsigned pre_lvl = 0;
+  static_assert(IT_NTHR == 64 * 64 / 8 && IT_NTHR == 2 * 32 * 32 / 4 && IT_MAX_ITEMS <= IT_NTHR && IT_MAX_LEVELS <= IT_NTHR,
+                "one residual vector, one block and one level count per lane");
+  {
+    const int ty = tid >> 3, tx = (tid & 7) * 8;
+    if (ctux + tx < s.w && ctuy + ty < s.h) pre_ry = *(const uint4 *)&J.resi[0][(size_t)(ctuy + ty) * s.stride_y + ctux + tx];
+    const int c = tid >> 8, i = tid & 255, cty = i >> 3, ctx = (i & 7) * 4;
+    if ((ctux >> 1) + ctx < s.cw && (ctuy >> 1) + cty < s.ch)
+      pre_rc = *(const uint2 *)&J.resi[1 + c][(size_t)((ctuy >> 1) + cty) * s.stride_c + (ctux >> 1) + ctx];
+    if (tid < nit) pre_item = *(const uint4 *)&J.intra[ci.item_start + tid];
+    if (tid < ci.n_lvl && tid < IT_MAX_LEVELS) pre_lvl = J.lvl_counts[ci.lvl_start + tid];
+  }
   if (tid == 0) {
     if (ci.n_items > IT_MAX_ITEMS || ci.n_lvl > IT_MAX_LEVELS) atomicOr(J.error_flag, HR_ERR_INTRA_CAPACITY);
     if (ci.deps) {
@@ -1406,6 +1447,7 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
     }
   }
   __syncthreads();
+  HR_STAMP(1)
 
   // ---- stage the CTU and its top / left borders in LDS ----
   // An all-intra picture writes every sample of the CTU before reading it, so only the borders are needed.
@@ -1474,24 +1516,15 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
         if (gx >= 0 && gy < s.ch) tile_c[c][(j + 1) * IT_CW] = ((const pel_t *)J.rec[1 + c])[(size_t)gy * s.stride_c + gx];
       }
     }
-    // residual of the CTU's coded intra blocks (positions without one hold garbage and are never read)
-    for (int i = tid; i < 64 * 64 / 8; i += IT_NTHR) {
-      const int ty = i >> 3, tx = (i & 7) * 8;
-      const int gx = ctux + tx, gy = ctuy + ty;
-      if (gx < s.w && gy < s.h) *(uint4 *)&resi_y[ty * 64 + tx] = *(const uint4 *)&J.resi[0][(size_t)gy * s.stride_y + gx];
-    }
-#pragma unroll
-    for (int c = 0; c < 2; c++)
-      for (int i = tid; i < 32 * 32 / 4; i += IT_NTHR) {
-        const int ty = i >> 3, tx = (i & 7) * 4;
-        const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
-        if (gx < s.cw && gy < s.ch) *(uint2 *)&resi_c[c][ty * 32 + tx] = *(const uint2 *)&J.resi[1 + c][(size_t)gy * s.stride_c + gx];
-      }
-    const int nit = ci.n_items < IT_MAX_ITEMS ? ci.n_items : IT_MAX_ITEMS;
-    for (int i = tid; i < nit; i += IT_NTHR) items_s[i] = J.intra[ci.item_start + i];
-    for (int i = tid; i < ci.n_lvl && i < IT_MAX_LEVELS; i += IT_NTHR) lvlc_s[i] = J.lvl_counts[ci.lvl_start + i];
+    // residual of the CTU's coded intra blocks (positions without one hold garbage and are never read), block list
+    // and level counts: fetched above
+    *(uint4 *)&resi_y[(tid >> 3) * 64 + (tid & 7) * 8] = pre_ry;
+    *(uint2 *)&resi_c[tid >> 8][((tid & 255) >> 3) * 32 + (tid & 7) * 4] = pre_rc;
+    if (tid < nit) *(uint4 *)&items_s[tid] = pre_item;
+    if (tid < ci.n_lvl && tid < IT_MAX_LEVELS) lvlc_s[tid] = (uint16_t)pre_lvl;
   }
   __syncthreads();
+  HR_STAMP(2)
 
   int base = 0;
   const int n_lvl = ci.n_lvl < IT_MAX_LEVELS ? ci.n_lvl : IT_MAX_LEVELS;
@@ -1675,6 +1708,7 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
     }
     base += cnt;
   }
+  HR_STAMP(3)
   // ---- write the CTU back (in P/B pictures the inter samples staged above go back unchanged) ----
   // Eight bytes per store, written through to memory: a neighbouring CTU may be waiting for these samples in another
   // workgroup of this launch.  (Picture widths are multiples of 8 luma samples; a chroma store that begins inside
@@ -1703,9 +1737,14 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
       }
     }
   }
+  HR_STAMP(4)
   hr_drain_stores();
   __syncthreads();
   if (tid == 0) hr_flag_raise(J.ctu_done + (size_t)ci.cy * s.ctus_w + ci.cx);
+  HR_STAMP(5)
+#ifdef HEVCRECON_INTRA_STAMPS
+  if (tid == 0) atomicAdd(&hr_intra_stamps[6], 1ull);
+#endif
   }  // next CTU
 }
 
