@@ -1407,44 +1407,45 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
     if (tid < nit) pre_item = *(const uint4 *)&J.intra[ci.item_start + tid];
     if (tid < ci.n_lvl && tid < IT_MAX_LEVELS) pre_lvl = J.lvl_counts[ci.lvl_start + tid];
   }
-  if (tid == 0) {
-    if (ci.n_items > IT_MAX_ITEMS || ci.n_lvl > IT_MAX_LEVELS) atomicOr(J.error_flag, HR_ERR_INTRA_CAPACITY);
-    if (ci.deps) {
-      // the neighbouring CTUs whose intra blocks this one reads: left, above-left, above, above-right
-      const unsigned *done = J.ctu_done + (size_t)ci.cy * s.ctus_w + ci.cx;
-      const int at[4] = {-1, -s.ctus_w - 1, -s.ctus_w, -s.ctus_w + 1};
-      bool timed_out = false;
-      unsigned spins = 0;
-      unsigned long long t0 = 0;
-#pragma unroll
-      for (int d = 0; d < 4; d++)
-        if (ci.deps & (1 << d)) {
-          while (hr_flag_read(done + at[d]) == 0) {
-            // Bounded: after 20 s without progress (or, where there is no clock, 2^26 polls) the neighbour is taken
-            // never to finish (a corrupt list) and the launch gives up instead of hanging.
-            if ((++spins & 0xfff) == 0) {
-              const unsigned long long now = hr_clock100();
-              if (t0 == 0) t0 = now;
-              if (now - t0 > 2000000000ull || spins >= (1u << 26)) {
-                timed_out = true;
-                if (atomicOr(J.error_flag + 1, 1) == 0) {  // first report: which entry waited for which neighbour
-                  J.error_flag[2] = (int)entry_idx;
-                  J.error_flag[3] = (int)entry;
-                  J.error_flag[4] = d;
-                  J.error_flag[5] = (int)hr_flag_read(ticket);
-                  J.error_flag[6] = n_items;
-                  J.error_flag[7] = ci.cx | (ci.cy << 8) | (ci.deps << 16);
-                }
-                break;
-              }
-            }
-            hr_nap();
+  if (tid == 0 && (ci.n_items > IT_MAX_ITEMS || ci.n_lvl > IT_MAX_LEVELS)) atomicOr(J.error_flag, HR_ERR_INTRA_CAPACITY);
+  if (wv == 0 && ci.deps) {
+    // the neighbouring CTUs whose intra blocks this one reads: left, above-left, above, above-right; lane d of the
+    // first wave watches neighbour d, so that the four flags are read side by side
+    const int d = lane & 3;
+    const int at = d == 0 ? -1 : d == 1 ? -s.ctus_w - 1 : d == 2 ? -s.ctus_w : -s.ctus_w + 1;
+    const unsigned *flag = J.ctu_done + (size_t)ci.cy * s.ctus_w + ci.cx + at;
+    bool waiting = lane < 4 && ((ci.deps >> d) & 1) != 0;
+    bool timed_out = false;
+    unsigned spins = 0;
+    unsigned long long t0 = 0;
+    for (;;) {
+      if (waiting && hr_flag_read(flag) != 0) waiting = false;
+      if (!__any(waiting)) break;
+      // Bounded: after 20 s without progress (or, where there is no clock, 2^26 polls) the neighbour is taken
+      // never to finish (a corrupt list) and the launch gives up instead of hanging.
+      if ((++spins & 0xfff) == 0) {
+        const unsigned long long now = hr_clock100();
+        if (t0 == 0) t0 = now;
+        if (now - t0 > 2000000000ull || spins >= (1u << 26)) {
+          timed_out = true;
+          if (waiting && atomicOr(J.error_flag + 1, 1) == 0) {  // first report: which entry waited for which neighbour
+            J.error_flag[2] = (int)entry_idx;
+            J.error_flag[3] = (int)entry;
+            J.error_flag[4] = d;
+            J.error_flag[5] = (int)hr_flag_read(ticket);
+            J.error_flag[6] = n_items;
+            J.error_flag[7] = ci.cx | (ci.cy << 8) | (ci.deps << 16);
           }
+          break;
         }
+      }
+      hr_nap();
+    }
+    if (lane == 0) {
       if (spins > 4096) atomicMax(J.error_flag + 8, (int)spins);  // longest wait of the launch, for tuning the bound
       if (timed_out) atomicOr(J.error_flag, HR_ERR_INTRA_TIMEOUT);
-      hr_acquire();
     }
+    hr_acquire();
   }
   __syncthreads();
   HR_STAMP(1)
