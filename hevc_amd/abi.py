@@ -13,7 +13,8 @@ PARTS_PER_CTU = 256
 NUM_KERNELS = 11
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhevcrecon.so")
+# HEVCRECON_LIB names another build of the library (diagnostic variants); the default is the in-tree one
+LIB_PATH = os.environ.get("HEVCRECON_LIB") or os.path.join(_HERE, "libhevcrecon.so")
 
 
 class SeqParams(C.Structure):

@@ -81,6 +81,16 @@ struct McBlk {
 // its longest dependency chain (all blocks 4x4) has 90 links; the packer refuses anything beyond.
 #define HR_INTRA_MAX_ITEMS 384
 #define HR_INTRA_MAX_LEVELS 96
+// The intra kernel takes a CTU's blocks in rounds: up to HR_INTRA_ROUND_BLOCKS blocks of one local level, one wave
+// each.  (90 levels and 384 blocks give at most 90 + 384 / 8 rounds.)
+#define HR_INTRA_ROUND_BLOCKS 8
+#define HR_INTRA_MAX_ROUNDS 144
+// A round as the kernel reads it: first block (relative to the CTU's first), number of blocks, and whether the round
+// holds a 32x32 block (its prediction is then spread over all waves)
+#define IR_BASE_MASK 0x1ff
+#define IR_COUNT_SHIFT 9
+#define IR_COUNT_MASK 0xf
+#define IR_BIG 0x2000
 
 #define IN_CORNER 0x01
 #define IN_HAS_RESI 0x02
@@ -93,8 +103,21 @@ struct IntraItem {
   uint8_t flags;
   uint16_t avail_left; /* bit j: unit j of the left column, from the top; units [n/u, 2n/u) are below-left */
   uint16_t avail_above; /* bit i: unit i of the row above, from the left; units [n/u, 2n/u) are above-right */
-  uint32_t resi_off;
+  uint32_t prep;        /* derived from the fields above when the picture closes (IP_*), so that the kernel need not */
 };
+
+// IntraItem.prep.  The 4n+1 reference samples are numbered from the bottom of the left column (0) over the corner
+// (2n) to the right end of the row above (4n).  When the available ones form one run [first, last], sample i is
+// read from position clamp(i, first, last) (TLibCommon/TComPattern.cpp:424-435,546-588 substitute exactly so).
+#define IP_FIRST_SHIFT 0  /* 8 bits: first available sample (also with holes: it stands in for everything before it) */
+#define IP_LAST_SHIFT 8   /* 8 bits: last available sample */
+#define IP_KIND_SHIFT 16  /* 2 bits: IP_KIND_* */
+#define IP_KIND_NONE 0    /* nothing available: every sample is 1 << (bit depth - 1) */
+#define IP_KIND_RUN 1     /* one run of available samples */
+#define IP_KIND_HOLES 2   /* anything else: resolved per sample from the unit masks */
+#define IP_FILTER 0x40000 /* bit 18: the block predicts from smoothed samples (TComPattern::getPredictorPtr) */
+#define IP_ANGLE_SHIFT 19 /* 7 bits: intraPredAngle + 32 (angular modes; negative for horizontal modes means the same as for vertical) */
+#define IP_ABS_SHIFT 26   /* 4 bits: |mode - 10| or |mode - 26|, whichever applies (index of the inverse-angle table) */
 
 /* IntraCtu.deps: neighbouring CTUs whose intra blocks this CTU's blocks read (it has to wait for them) */
 #define IC_DEP_LEFT 1
@@ -110,6 +133,9 @@ struct IntraCtu {
   uint8_t cx, cy;      /* CTU position in CTUs (pictures are at most 8192 samples = 128 CTUs wide and high) */
   uint8_t deps;        /* IC_DEP_* */
   uint8_t pad;
+  uint32_t round_start; /* first entry of this CTU in rounds[] */
+  uint16_t n_rounds;
+  uint16_t pad2;
 };
 
 // De-quantisation matrices of a picture that uses scaling lists (same content as hevcrecon_scaling_lists).
@@ -180,7 +206,7 @@ struct PicJob {
                        only positions covered by a coded intra block are ever written or read */
   const IntraItem *intra;
   const IntraCtu *ictu;
-  const uint16_t *lvl_counts; /* per CTU: number of intra blocks at each local level */
+  const uint16_t *rounds;     /* per CTU: its rounds (IR_*), level by level */
   const int32_t *wave_off;    /* n_waves + 1 entries into ictu[] */
   int32_t n_waves;
   uint32_t *ctu_done;         /* one word per CTU (raster), zero when the batch starts: set by the intra kernel once the

@@ -685,7 +685,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   s->off_coeff = place(k.coeff.size() * sizeof(uint32_t));
   s->off_intra = place(k.intra.size() * sizeof(IntraItem));
   s->off_ictu = place(k.ictu.size() * sizeof(IntraCtu));
-  s->off_lvlc = place(k.lvl_counts.size() * sizeof(uint16_t));
+  s->off_lvlc = place(k.rounds.size() * sizeof(uint16_t));
   s->off_wave = place(k.wave_off.size() * sizeof(int32_t));
   s->off_sao = place(k.sao.size() * sizeof(SaoCtu));
   s->off_ctui = place(k.ctu_info.size() * sizeof(CtuInfo));
@@ -730,7 +730,7 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   std::memcpy(s->up_host + s->off_coeff, k.coeff.data(), k.coeff.size() * sizeof(uint32_t));
   std::memcpy(s->up_host + s->off_intra, k.intra.data(), k.intra.size() * sizeof(IntraItem));
   std::memcpy(s->up_host + s->off_ictu, k.ictu.data(), k.ictu.size() * sizeof(IntraCtu));
-  std::memcpy(s->up_host + s->off_lvlc, k.lvl_counts.data(), k.lvl_counts.size() * sizeof(uint16_t));
+  std::memcpy(s->up_host + s->off_lvlc, k.rounds.data(), k.rounds.size() * sizeof(uint16_t));
   std::memcpy(s->up_host + s->off_wave, k.wave_off.data(), k.wave_off.size() * sizeof(int32_t));
   std::memcpy(s->up_host + s->off_sao, k.sao.data(), k.sao.size() * sizeof(SaoCtu));
   std::memcpy(s->up_host + s->off_ctui, k.ctu_info.data(), k.ctu_info.size() * sizeof(CtuInfo));
@@ -790,14 +790,13 @@ extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[32]
   out[29] = (int64_t)s->upload_bytes;
   out[30] = (int64_t)k.runs.size();
   out[10] = k.finished ? 1 : 0;
-  // intra schedule: rounds of 4 blocks on the critical path (slowest CTU of every wave) and in total
+  // intra schedule: rounds on the critical path (slowest CTU of every wave) and in total
   if (k.finished && !k.wave_off.empty()) {
     int64_t crit = 0, total = 0, crit_lvl = 0;
     for (size_t w = 0; w + 1 < k.wave_off.size(); w++) {
       int64_t worst = 0, worst_lvl = 0;
       for (int i = k.wave_off[w]; i < k.wave_off[w + 1]; i++) {
-        int64_t r = 0;
-        for (int l = 0; l < k.ictu[i].n_lvl; l++) r += (k.lvl_counts[k.ictu[i].lvl_start + l] + 3) / 4;
+        const int64_t r = k.ictu[i].n_rounds;
         total += r;
         if (r > worst) worst = r;
         if (k.ictu[i].n_lvl > worst_lvl) worst_lvl = k.ictu[i].n_lvl;
@@ -914,7 +913,7 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
     for (int p = 0; p < 3; p++) j.resi[p] = (int16_t *)((char *)ws.resi_base[i] + c->resi_off[p]);
     j.intra = (const IntraItem *)(y->up_dev + y->off_intra);
     j.ictu = (const IntraCtu *)(y->up_dev + y->off_ictu);
-    j.lvl_counts = (const uint16_t *)(y->up_dev + y->off_lvlc);
+    j.rounds = (const uint16_t *)(y->up_dev + y->off_lvlc);
     j.wave_off = (const int32_t *)(y->up_dev + y->off_wave);
     j.n_waves = k.wave_off.empty() ? 0 : (int)k.wave_off.size() - 1;
     if (j.n_waves > max_levels) max_levels = j.n_waves;

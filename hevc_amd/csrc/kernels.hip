@@ -1212,44 +1212,197 @@ __device__ __forceinline__ void transform_blocks(const PicJob &J, const SeqInfo 
   }
 }
 
-// Angular prediction of one sample from main-reference index i0 (>= 0 for positive angles) and fraction df.
-__device__ __forceinline__ int intra_ang_pos(const int *cn, int sgn, int i0, int df) {
-  const int a0 = cn[sgn * i0], a1 = cn[sgn * (i0 + 1)];
-  return df ? (__mul24(32 - df, a0) + __mul24(df, a1) + 16) >> 5 : a0;
+// ---- wave-level helpers of the intra kernel: neighbouring lanes' values and a sum over the wave, without LDS traffic
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ int hr_lane_prev(int v) { return __shfl(v, (emu::lane() + 63) & 63); }  // lane 0: unspecified
+__device__ __forceinline__ int hr_lane_next(int v) { return __shfl(v, (emu::lane() + 1) & 63); }   // lane 63: unspecified
+__device__ __forceinline__ int hr_wave_sum(int v) {
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
 }
-__device__ __forceinline__ int intra_ang_neg(const int *cn, int sgn, int inv, int i0, int df) {
-  const int i1 = i0 + 1;
-  const int a0 = i0 >= 0 ? cn[sgn * i0] : cn[-sgn * ((128 - __mul24(i0, inv)) >> 8)];
-  const int a1 = i1 >= 0 ? cn[sgn * i1] : cn[-sgn * ((128 - __mul24(i1, inv)) >> 8)];
-  return df ? (__mul24(32 - df, a0) + __mul24(df, a1) + 16) >> 5 : a0;
+#else
+__device__ __forceinline__ int hr_lane_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ int hr_lane_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ int hr_wave_sum(int v) {
+  // running sums inside each row of 16 lanes (row_shr:1,2,4,8, zeros shifted in), then the four row totals
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  return hr_readlane(v, 15) + hr_readlane(v, 31) + hr_readlane(v, 47) + hr_readlane(v, 63);
 }
+#endif
 
-#define IT_WAVES 8 /* waves per workgroup (power of two) = blocks per round */
+#define IT_WAVES HR_INTRA_ROUND_BLOCKS /* waves per workgroup (power of two) = blocks per round */
 #define IT_NTHR (IT_WAVES * 64)
 #define IT_YW 100 /* luma tile row: x = -1 .. 96 (97 used) */
 #define IT_CW 52  /* chroma tile row: x = -1 .. 48 (49 used) */
-// Prediction + residual + clip of the samples p_first, p_first + p_step, ... (raster inside the block) of one intra block,
-// written into the CTU tile (TLibCommon/TComPrediction.cpp:183-390,691-763).  w0 / w1: the block's first two item
-// words; refs: its reference samples (smoothed or not, as the block's mode asks).
-__device__ __forceinline__ void intra_predict(const SeqInfo &s, uint16_t *tile_y, uint16_t *tile_cb, uint16_t *tile_cr, const int16_t *resi_y,
+#define IT_REFW 136 /* reference samples of a block: 4 * 32 + 1, rounded up */
+
+// invAngle by |mode - 26| (or |mode - 10|), TLibCommon/TComPrediction.cpp:226-230
+__constant__ int kIntraInvAngle[16] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256, 0, 0, 0, 0, 0, 0, 0};
+
+// One wave builds the reference samples r[0 .. 4n] of a block (r[2n] is the corner, r[2n-1-j] the left column going
+// down, r[2n+1+i] the row above going right: TComPattern::initAdiPattern / fillReferenceSamples,
+// TLibCommon/TComPattern.cpp:213-602): gathered from the CTU tile with unavailable samples substituted, smoothed when
+// the block's mode asks for it (only the version the block predicts from is kept), stored to ref[].  Lane l holds
+// samples l, l + 64 and l + 128.  Everything but `lane` is the same in all lanes.  Returns the DC value (mode 1).
+// base_off: tile position of the corner sample.
+__device__ __forceinline__ int intra_references(const uint16_t *tile, int tw, int base_off, int log2n, int comp, int mode, int flags, unsigned w2,
+                                                unsigned w3, int bd, int strong_intra, uint16_t *ref, int lane) {
+  const int n = 1 << log2n, len = 4 * n + 1;
+  const int kind = (w3 >> IP_KIND_SHIFT) & 3;
+  const int first_i = (w3 >> IP_FIRST_SHIFT) & 255, last_i = (w3 >> IP_LAST_SHIFT) & 255;
+  int v[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) v[k] = 1 << (bd - 1);
+  if (kind != IP_KIND_NONE) {
+    int src[3];
+    if (kind == IP_KIND_RUN) {
+      // the available samples form one run: what lies before it takes its first sample, what lies after it its last
+#pragma unroll
+      for (int k = 0; k < 3; k++) src[k] = min(max(lane + 64 * k, first_i), last_i);
+    } else {
+      // holes (slice and tile corners, constrained intra prediction): per sample from the unit masks.  Availability
+      // of the 4*nu+1 units in sample order: units 0..31 in m, the 33rd unit of a 32x32 luma block in m_top
+      const int lus = comp ? 1 : 2, us = 1 << lus, nu = n >> lus;
+      const unsigned long long m64 = (unsigned long long)(hr_brev(w2 & 0xffff) >> (32 - 2 * nu)) |
+                                     ((flags & IN_CORNER) ? 1ull << (2 * nu) : 0ull) |
+                                     ((unsigned long long)((w2 >> 16) & ((1u << (2 * nu)) - 1)) << (2 * nu + 1));
+      const unsigned m = (unsigned)m64;
+      const bool m_top = (m64 >> 32) != 0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const int i = min(lane + 64 * k, len - 1);
+        const int u = i < 2 * n ? i >> lus : (i == 2 * n ? 2 * nu : 2 * nu + 1 + ((i - 2 * n - 1) >> lus));
+        int sk = i;
+        const bool avail = u < 32 ? ((m >> u) & 1) != 0 : m_top;
+        if (!avail) {
+          const unsigned below = u < 32 ? m & ((1u << u) - 1) : m;
+          if (below) {
+            const int ub = 31 - __clz((int)below);  // nearest available unit before this one: its last sample
+            sk = ub < 2 * nu ? (ub << lus) + us - 1 : (ub == 2 * nu ? 2 * n : 2 * n + 1 + ((ub - 2 * nu - 1) << lus) + us - 1);
+          } else {
+            sk = first_i;
+          }
+        }
+        src[k] = sk;
+      }
+    }
+    // sample number -> tile position: the left column runs upwards to the corner, the row above runs right from it;
+    // all reads are issued before the first is used
+    int off[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int d = src[k] - 2 * n;
+      off[k] = base_off + max(d, __mul24(d, -tw));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+      if (64 * k < len) v[k] = tile[off[k]];
+  }
+  int out[3] = {v[0], v[1], v[2]};
+  int dcv = 0;
+  if (w3 & IP_FILTER) {
+    // [1 2 1] smoothing, or the bilinear one of flat 32x32 blocks; the end samples stay (TComPattern.cpp:263-356)
+    int r0 = 0, r2n = 0, r4n = 0;
+    bool strong = false;
+    if (log2n == 5 && strong_intra) {
+      r0 = hr_readlane(v[0], 0);
+      r2n = hr_readlane(v[1], 0);
+      r4n = hr_readlane(v[2], 0);
+      const int rn = hr_readlane(v[0], 32), r3n = hr_readlane(v[1], 32), thr = 1 << (bd - 5);
+      strong = iabs(r0 + r2n - 2 * rn) < thr && iabs(r2n + r4n - 2 * r3n) < thr;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (64 * k >= len) continue;
+      const int i = lane + 64 * k;
+      // neighbours across the 64-sample slots come from the other slot's end lane
+      int p = hr_lane_prev(v[k]), nx = hr_lane_next(v[k]);
+      if (k > 0) {
+        const int edge_p = hr_readlane(v[k - 1], 63);
+        p = lane == 0 ? edge_p : p;
+      }
+      if (k < 2 && 64 * (k + 1) < len) {
+        const int edge_n = hr_readlane(v[k + 1], 0);
+        nx = lane == 63 ? edge_n : nx;
+      }
+      int f = (p + 2 * v[k] + nx + 2) >> 2;
+      if (strong) f = k == 0 ? ((64 - lane) * r0 + lane * r2n + 32) >> 6 : ((64 - lane) * r2n + lane * r4n + 32) >> 6;
+      out[k] = (i == 0 || i >= len - 1) ? v[k] : f;
+    }
+  } else if (mode == 1) {
+    // DC value: mean of the n samples above and the n samples to the left (TLibCommon/TComPrediction.cpp:122-160)
+    int part = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int i = lane + 64 * k;
+      if (i >= n && i <= 3 * n && i != 2 * n) part += v[k];
+    }
+    dcv = (hr_wave_sum(part) + n) >> (log2n + 1);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++)
+    if (lane + 64 * k < len) ref[lane + 64 * k] = (uint16_t)out[k];
+  return dcv;
+}
+
+// A block as the prediction sees it; the same in every lane.
+struct IntraBlk {
+  int log2n, mode, angle, inv, tw, rw, maxv, dcv;
+  bool edge, has_resi;
+  uint16_t *tile0;        // the block's first sample in the CTU tile
+  const int16_t *resi0;   // its residual
+  const uint16_t *cn;     // its reference samples: cn[0] corner, cn[-1-j] left[j], cn[1+i] above[i]
+};
+__device__ __forceinline__ IntraBlk intra_blk(const SeqInfo &s, uint16_t *tile_y, uint16_t *tile_cb, uint16_t *tile_cr, const int16_t *resi_y,
                                               const int16_t *resi_cb, const int16_t *resi_cr, int ctux, int ctuy, unsigned w0, unsigned w1,
-                                              const int *refs, int dcv, int p_first, int p_step) {
-    const int log2n = w1 & 255;
-    const int n = 1 << log2n, npx = n * n;
-    const int x0 = w0 & 0xffff, y0 = w0 >> 16;
-    const int comp = (w1 >> 8) & 255, mode = (w1 >> 16) & 255, flags = w1 >> 24;
-    const int sh = comp ? 1 : 0;
-    const int bd = comp ? s.bd_c : s.bd_y, maxv = (1 << bd) - 1;
-    uint16_t *tile = comp == 0 ? tile_y : comp == 1 ? tile_cb : tile_cr;
-    const int tw = comp ? IT_CW : IT_YW;
-    const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
-    const int *cn = refs + 2 * n;  // cn[0] corner, cn[-1-j] left[j], cn[1+i] above[i]
-    const bool edge = comp == 0 && n <= 16;
-    const int16_t *resi = comp == 0 ? resi_y : comp == 1 ? resi_cb : resi_cr;
-    const int rw = comp ? 32 : 64;
-    const bool has_resi = (flags & IN_HAS_RESI) != 0;
-    const int16_t *resi0 = resi + (ty0 - 1) * rw + tx0 - 1;
-    uint16_t *tile0 = tile + ty0 * tw + tx0;
+                                              unsigned w3, int dcv, const uint16_t *refs) {
+  IntraBlk B;
+  B.log2n = w1 & 255;
+  const int n = 1 << B.log2n;
+  const int x0 = w0 & 0xffff, y0 = w0 >> 16;
+  const int comp = (w1 >> 8) & 255, flags = w1 >> 24;
+  B.mode = (w1 >> 16) & 255;
+  const int sh = comp ? 1 : 0;
+  B.maxv = (1 << (comp ? s.bd_c : s.bd_y)) - 1;
+  B.tw = comp ? IT_CW : IT_YW;
+  B.rw = comp ? 32 : 64;
+  const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
+  B.tile0 = (comp == 0 ? tile_y : comp == 1 ? tile_cb : tile_cr) + ty0 * B.tw + tx0;
+  B.resi0 = (comp == 0 ? resi_y : comp == 1 ? resi_cb : resi_cr) + (ty0 - 1) * B.rw + tx0 - 1;
+  B.cn = refs + 2 * n;
+  B.edge = comp == 0 && n <= 16;
+  B.has_resi = (flags & IN_HAS_RESI) != 0;
+  B.angle = (int)((w3 >> IP_ANGLE_SHIFT) & 127) - 32;
+  B.inv = kIntraInvAngle[(w3 >> IP_ABS_SHIFT) & 15];
+  B.dcv = dcv;
+  return B;
+}
+
+// Angular prediction of one sample from main-reference index i0 (>= 0 for positive angles) and fraction df.
+// (df = 0 gives a0 exactly, so the interpolation needs no special case.)
+__device__ __forceinline__ int intra_ang_pos(const uint16_t *cn, int sgn, int i0, int df) {
+  const int a0 = cn[sgn * i0], a1 = cn[sgn * (i0 + 1)];
+  return (__mul24(32 - df, a0) + __mul24(df, a1) + 16) >> 5;
+}
+__device__ __forceinline__ int intra_ang_neg(const uint16_t *cn, int sgn, int inv, int i0, int df) {
+  const int i1 = i0 + 1;
+  const int a0 = i0 >= 0 ? cn[sgn * i0] : cn[-sgn * ((128 - __mul24(i0, inv)) >> 8)];
+  const int a1 = i1 >= 0 ? cn[sgn * i1] : cn[-sgn * ((128 - __mul24(i1, inv)) >> 8)];
+  return (__mul24(32 - df, a0) + __mul24(df, a1) + 16) >> 5;
+}
+
+// Prediction + residual + clip of the samples p_first, p_first + p_step, ... (raster inside the block) of one intra block,
+// written into the CTU tile (TLibCommon/TComPrediction.cpp:183-390,691-763).
+__device__ __forceinline__ void intra_predict(const IntraBlk &B, int p_first, int p_step) {
+    const int log2n = B.log2n, n = 1 << log2n, npx = n * n;
+    const int mode = B.mode, maxv = B.maxv, tw = B.tw, rw = B.rw, dcv = B.dcv;
+    const uint16_t *cn = B.cn;
+    const int16_t *resi0 = B.resi0;
+    uint16_t *tile0 = B.tile0;
+    const bool has_resi = B.has_resi, edge = B.edge;
 #define INTRA_STORE_LOOP(EXPR)                                       \
   for (int p = p_first; p < npx; p += p_step) {                      \
 const int py = p >> log2n, px = p & (n - 1);                     \
@@ -1273,11 +1426,7 @@ tile0[py * tw + px] = (uint16_t)clip3i(0, maxv, v);              \
       // angular: vertical modes predict from the row above, horizontal modes are the same computation
       // on the transposed block (main = left column): sgn flips the index direction
       const bool hor = mode < 18;
-      const int a = hor ? -(mode - 10) : mode - 26;
-      const int aa = iabs(a);
-      const int at = aa == 0 ? 0 : aa == 1 ? 2 : aa == 2 ? 5 : aa == 3 ? 9 : aa == 4 ? 13 : aa == 5 ? 17 : aa == 6 ? 21 : aa == 7 ? 26 : 32;
-      const int inv = aa == 0 ? 0 : aa == 1 ? 4096 : aa == 2 ? 1638 : aa == 3 ? 910 : aa == 4 ? 630 : aa == 5 ? 482 : aa == 6 ? 390 : aa == 7 ? 315 : 256;
-      const int angle = a < 0 ? -at : at;
+      const int angle = B.angle, inv = B.inv;
       const int sgn = hor ? -1 : 1;  // MAIN(i) = cn[sgn * i], SIDE(i) = cn[-sgn * i]
 #define KK (hor ? px : py) /* index along the prediction direction */
 #define EE (hor ? py : px) /* index across it */
@@ -1337,23 +1486,24 @@ __global__ __launch_bounds__(256) void k_transform_small(const PicJob *jobs, Seq
 // r[2n+1+i] the row above going right (TComPattern::initAdiPattern / fillReferenceSamples,
 // TLibCommon/TComPattern.cpp:213-602).  Availability comes per 4-luma-sample unit from the packer.
 #define IT_MAX_ITEMS HR_INTRA_MAX_ITEMS
-#define IT_MAX_LEVELS HR_INTRA_MAX_LEVELS
+#define IT_MAX_ROUNDS HR_INTRA_MAX_ROUNDS
 
 // Diagnostic build only (-DHEVCRECON_INTRA_STAMPS): cycles that lane 0 of every workgroup spends in each phase of a
 // CTU, summed over the launch; read back and printed by hr_intra_stamps_report().
 #ifdef HEVCRECON_INTRA_STAMPS
-__device__ unsigned long long hr_intra_stamps[8];
+__device__ unsigned long long hr_intra_stamps[16];
 #define HR_STAMP(k)                                                                   \
   if (tid == 0) {                                                                     \
     const unsigned long long now_ = __builtin_amdgcn_s_memtime();                     \
-    atomicAdd(&hr_intra_stamps[k], now_ - stamp_);                                    \
+    acc_[k] += now_ - stamp_;                                                         \
     stamp_ = now_;                                                                    \
   }
 void hr_intra_stamps_report() {
-  unsigned long long v[8];
+  unsigned long long v[16];
   if (hipMemcpyFromSymbol(v, HIP_SYMBOL(hr_intra_stamps), sizeof v) != hipSuccess) return;
-  const char *names[8] = {"ticket", "wait for neighbours", "staging", "rounds", "write-back issue", "drain + barrier", "CTUs", ""};
-  for (int k = 0; k < 7; k++) fprintf(stderr, "k_intra %-20s %llu\n", names[k], v[k]);
+  const char *names[16] = {"ticket", "wait for neighbours", "staging", "rounds (rest)", "write-back issue", "drain + barrier", "CTUs", "rounds",
+                           "round: set-up", "round: references", "round: barrier 1", "round: prediction", "round: barrier 2", "two-phase rounds", "", ""};
+  for (int k = 0; k < 14; k++) fprintf(stderr, "k_intra %-20s %llu\n", names[k], v[k]);
 }
 #else
 #define HR_STAMP(k)
@@ -1366,9 +1516,9 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
   __shared__ int16_t resi_y[64 * 64];
   __shared__ int16_t resi_c[2][32 * 32];
   __shared__ __attribute__((aligned(16))) IntraItem items_s[IT_MAX_ITEMS];
-  __shared__ uint16_t lvlc_s[IT_MAX_LEVELS];
-  __shared__ int ref_s[IT_WAVES][132], flt_s[IT_WAVES][132];
-  __shared__ unsigned blk_s[IT_WAVES][4];  // per block of the round: item words 0 and 1, filtered?, DC value
+  __shared__ uint16_t rounds_s[IT_MAX_ROUNDS];
+  __shared__ uint16_t ref_s[IT_WAVES][IT_REFW];
+  __shared__ __attribute__((aligned(16))) unsigned blk_s[IT_WAVES][4];  // per block of a two-phase round: item words 0, 1 and 3, DC value
   __shared__ unsigned ticket_s;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   // One launch per batch.  The batch's CTUs (those holding intra blocks) stand in a list ordered so that every CTU
@@ -1378,12 +1528,13 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
   // time, the earliest unfinished entry never waits for an entry that has not been drawn, so the launch drains.
 #ifdef HEVCRECON_INTRA_STAMPS
   unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+  unsigned long long acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // summed per workgroup, added to the totals once at the end
 #endif
   for (;;) {
   __syncthreads();  // the previous CTU's tile has been written back by every wave
   if (tid == 0) ticket_s = hr_ticket_take(ticket);
   __syncthreads();
-  const unsigned entry_idx = ticket_s;
+  const unsigned entry_idx = hr_uniform(ticket_s);  // the same in every lane: what follows from it stays in scalar registers
   if (entry_idx >= (unsigned)n_items) break;
   HR_STAMP(0)
   const unsigned entry = list ? list[entry_idx] : entry_idx;
@@ -1396,8 +1547,8 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
   uint4 pre_ry = make_uint4(0, 0, 0, 0), pre_item = make_uint4(0, 0, 0, 0);
   uint2 pre_rc = make_uint2(0, 0);
   unsigned pre_lvl = 0;
-  static_assert(IT_NTHR == 64 * 64 / 8 && IT_NTHR == 2 * 32 * 32 / 4 && IT_MAX_ITEMS <= IT_NTHR && IT_MAX_LEVELS <= IT_NTHR,
-                "one residual vector, one block and one level count per lane");
+  static_assert(IT_NTHR == 64 * 64 / 8 && IT_NTHR == 2 * 32 * 32 / 4 && IT_MAX_ITEMS <= IT_NTHR && IT_MAX_ROUNDS <= IT_NTHR,
+                "one residual vector, one block and one round per lane");
   {
     const int ty = tid >> 3, tx = (tid & 7) * 8;
     if (ctux + tx < s.w && ctuy + ty < s.h) pre_ry = *(const uint4 *)&J.resi[0][(size_t)(ctuy + ty) * s.stride_y + ctux + tx];
@@ -1405,9 +1556,9 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
     if ((ctux >> 1) + ctx < s.cw && (ctuy >> 1) + cty < s.ch)
       pre_rc = *(const uint2 *)&J.resi[1 + c][(size_t)((ctuy >> 1) + cty) * s.stride_c + (ctux >> 1) + ctx];
     if (tid < nit) pre_item = *(const uint4 *)&J.intra[ci.item_start + tid];
-    if (tid < ci.n_lvl && tid < IT_MAX_LEVELS) pre_lvl = J.lvl_counts[ci.lvl_start + tid];
+    if (tid < ci.n_rounds && tid < IT_MAX_ROUNDS) pre_lvl = J.rounds[ci.round_start + tid];
   }
-  if (tid == 0 && (ci.n_items > IT_MAX_ITEMS || ci.n_lvl > IT_MAX_LEVELS)) atomicOr(J.error_flag, HR_ERR_INTRA_CAPACITY);
+  if (tid == 0 && (ci.n_items > IT_MAX_ITEMS || ci.n_rounds > IT_MAX_ROUNDS)) atomicOr(J.error_flag, HR_ERR_INTRA_CAPACITY);
   if (wv == 0 && ci.deps) {
     // the neighbouring CTUs whose intra blocks this one reads: left, above-left, above, above-right; lane d of the
     // first wave watches neighbour d, so that the four flags are read side by side
@@ -1522,160 +1673,52 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
     *(uint4 *)&resi_y[(tid >> 3) * 64 + (tid & 7) * 8] = pre_ry;
     *(uint2 *)&resi_c[tid >> 8][((tid & 255) >> 3) * 32 + (tid & 7) * 4] = pre_rc;
     if (tid < nit) *(uint4 *)&items_s[tid] = pre_item;
-    if (tid < ci.n_lvl && tid < IT_MAX_LEVELS) lvlc_s[tid] = (uint16_t)pre_lvl;
+    if (tid < ci.n_rounds && tid < IT_MAX_ROUNDS) rounds_s[tid] = (uint16_t)pre_lvl;
   }
   __syncthreads();
   HR_STAMP(2)
 
-  int base = 0;
-  const int n_lvl = ci.n_lvl < IT_MAX_LEVELS ? ci.n_lvl : IT_MAX_LEVELS;
-  for (int lvl = 0; lvl < n_lvl; lvl++) {
-    const int cnt = hr_uniform((int)lvlc_s[lvl]);
-    for (int r0 = 0; r0 < cnt; r0 += IT_WAVES) {
-      const int nb = min(IT_WAVES, cnt - r0);  // blocks of this round
+  const int n_rounds = ci.n_rounds < IT_MAX_ROUNDS ? ci.n_rounds : IT_MAX_ROUNDS;
+  for (int r = 0; r < n_rounds; r++) {
+      // The round: its first block, how many, and whether a 32x32 block is among them (the packer's table).
       // A round without a 32x32 block is finished by the waves that build the references: each predicts its own
       // block (at most four passes of 64 samples) and the round costs one barrier.  The 16 passes of a 32x32 block
       // are worth spreading over all waves, at the price of a hand-over through LDS and a second barrier.
-      unsigned round_log2n = 0;
-      if (lane < nb && base + r0 + lane < IT_MAX_ITEMS) round_log2n = ((const unsigned *)&items_s[base + r0 + lane])[1] & 255;
-      const bool two_phase = __ballot(round_log2n == 5) != 0;
+      const unsigned rword = hr_uniform((unsigned)rounds_s[r]);
+      const int rbase = rword & IR_BASE_MASK, nb = min((int)((rword >> IR_COUNT_SHIFT) & IR_COUNT_MASK), IT_WAVES);
+      const bool two_phase = (rword & IR_BIG) != 0;
+      HR_STAMP(8)
       // ---- phase A: wave b builds the reference samples of block b ----
       if (wv < nb) {
-        int *ref = ref_s[wv], *flt = flt_s[wv];
-        const bool in_range = base + r0 + wv < IT_MAX_ITEMS;
+        const bool in_range = rbase + wv < nit;
         // The block's description is the same in every lane: keep it in scalar registers.
-        const unsigned *iw = (const unsigned *)&items_s[in_range ? base + r0 + wv : 0];
-        const unsigned w0 = hr_uniform(iw[0]), w1 = hr_uniform(iw[1]), w2 = hr_uniform(iw[2]);
+        const uint4 q = *(const uint4 *)&items_s[in_range ? rbase + wv : 0];
+        const unsigned w0 = hr_uniform(q.x), w1 = hr_uniform(q.y), w2 = hr_uniform(q.z), w3 = hr_uniform(q.w);
         const int x0 = w0 & 0xffff, y0 = w0 >> 16;
         const int log2n = w1 & 255, comp = (w1 >> 8) & 255, mode = (w1 >> 16) & 255, flags = w1 >> 24;
-        const int n = 1 << log2n;
-        const int sh = comp ? 1 : 0, lus = 2 - sh, us = 1 << lus, nu = n >> lus;
-        const int bd = comp ? s.bd_c : s.bd_y;
-        const uint16_t *tile = comp ? tile_c[comp - 1] : tile_y;
+        const int sh = comp ? 1 : 0;
         const int tw = comp ? IT_CW : IT_YW;
-        const int len = 4 * n + 1;
         // position of the block inside the tile (tile index 0 = sample -1 of the CTU)
         const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
-
-        // availability of the 4*nu+1 units in scan order (bottom-left ... corner ... top-right): units 0..31 in
-        // m, the 33rd unit of a 32x32 luma block (its last above-right unit) in m_top
-        const unsigned long long m64 = (unsigned long long)(hr_brev(w2 & 0xffff) >> (32 - 2 * nu)) |
-                                       ((flags & IN_CORNER) ? 1ull << (2 * nu) : 0ull) |
-                                       ((unsigned long long)((w2 >> 16) & ((1u << (2 * nu)) - 1)) << (2 * nu + 1));
-        const unsigned m = (unsigned)m64;
-        const bool m_top = (m64 >> 32) != 0;
-
-        // 1. reference samples with unavailable units substituted (TLibCommon/TComPattern.cpp:424-435,546-588):
-        //    every lane works out which sample stands in for its position from the mask alone and reads it
-        //    straight from the tile.
-        // (three fixed slots of 64 samples, all tile reads issued before the first result is used: the round's
-        // length is set by dependent LDS round trips, not by instruction count)
-        if (m64 == 0) {
-#pragma unroll
-          for (int k = 0; k < 3; k++)
-            if (lane + 64 * k < len) ref[lane + 64 * k] = 1 << (bd - 1);
-        } else {
-          const int ua = __ffsll((long long)m64) - 1;  // first available unit: its first sample stands in for everything before it
-          const int first_src = ua < 2 * nu ? ua << lus : (ua == 2 * nu ? 2 * n : 2 * n + 1 + ((ua - 2 * nu - 1) << lus));
-          int off[3] = {0, 0, 0};
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            if (64 * k >= len) continue;  // wave-uniform
-            const int i = min(lane + 64 * k, len - 1);
-            const int u = i < 2 * n ? i >> lus : (i == 2 * n ? 2 * nu : 2 * nu + 1 + ((i - 2 * n - 1) >> lus));
-            int src = i;
-            const bool avail = u < 32 ? ((m >> u) & 1) != 0 : m_top;
-            if (!avail) {
-              const unsigned below = u < 32 ? m & ((1u << u) - 1) : m;
-              if (below) {
-                const int ub = 31 - __clz((int)below);  // nearest available unit before this one: its last sample
-                src = ub < 2 * nu ? (ub << lus) + us - 1 : (ub == 2 * nu ? 2 * n : 2 * n + 1 + ((ub - 2 * nu - 1) << lus) + us - 1);
-              } else {
-                src = first_src;
-              }
-            }
-            // sample index -> tile coordinates: left column bottom-up, corner, row above left to right
-            const int sx = src <= 2 * n ? tx0 - 1 : tx0 + (src - 2 * n - 1);
-            const int sy = src < 2 * n ? ty0 + 2 * n - 1 - src : ty0 - 1;
-            off[k] = sy * tw + sx;
-          }
-          int v[3];
-#pragma unroll
-          for (int k = 0; k < 3; k++) v[k] = tile[off[k]];
-#pragma unroll
-          for (int k = 0; k < 3; k++)
-            if (lane + 64 * k < len) ref[lane + 64 * k] = v[k];
-        }
-        hr_wave_sync();
-        // 2. luma smoothing (TComPattern::getPredictorPtr :627-651 decides, :263-356 filters)
-        bool use_flt = false;
-        if (comp == 0 && mode != 1) {
-          const int thr = log2n == 2 ? 10 : log2n == 3 ? 7 : log2n == 4 ? 1 : 0;
-          use_flt = min(iabs(mode - 10), iabs(mode - 26)) > thr;
-        }
-        int dcv = 0;
-        if (use_flt) {
-          // every read of the smoothing step is issued before the first is used
-          const int r0 = ref[0], rn = ref[n], r2n = ref[2 * n], r3n = ref[3 * n], r4n = ref[4 * n];
-          int a[3], b[3], c[3];
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const int i = min(max(lane + 64 * k, 1), len - 2);  // in range for every lane, used or not
-            a[k] = ref[i - 1];
-            b[k] = ref[i];
-            c[k] = ref[i + 1];
-          }
-          bool strong = false;
-          if (s.strong_intra && n >= 32) {
-            const int thr = 1 << (bd - 5);
-            strong = iabs(r0 + r2n - 2 * rn) < thr && iabs(r2n + r4n - 2 * r3n) < thr;
-          }
-#pragma unroll
-          for (int k = 0; k < 3; k++) {
-            const int i = lane + 64 * k;
-            if (i >= len) continue;
-            int v;
-            if (i == 0) {
-              v = r0;
-            } else if (i == len - 1) {
-              v = r4n;
-            } else if (strong) {
-              // bilinear between the three corners; n = 32 so the shift is log2(2n) = 6
-              if (i < 2 * n)
-                v = ((2 * n - i) * r0 + i * r2n + n) >> 6;
-              else if (i == 2 * n)
-                v = r2n;
-              else
-                v = ((2 * n - (i - 2 * n)) * r2n + (i - 2 * n) * r4n + n) >> 6;
-            } else {
-              v = (a[k] + 2 * b[k] + c[k] + 2) >> 2;
-            }
-            flt[i] = v;
-          }
-        } else if (mode == 1) {
-          // DC value: wave reduction over the 2n neighbours (TLibCommon/TComPrediction.cpp:122-160)
-          const int *cn = ref + 2 * n;
-          int part = 0;
-          if (lane < 2 * n) part = lane < n ? cn[1 + lane] : cn[-1 - (lane - n)];
-#pragma unroll
-          for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
-          dcv = (part + n) >> (log2n + 1);
-        }
+        const int dcv = intra_references(comp ? tile_c[comp - 1] : tile_y, tw, (ty0 - 1) * tw + tx0 - 1, log2n, comp, mode, flags, w2, w3,
+                                         comp ? s.bd_c : s.bd_y, s.strong_intra, ref_s[wv], lane);
         if (two_phase) {
           if (lane == 0) {
             blk_s[wv][0] = w0;
             blk_s[wv][1] = in_range ? w1 : 0u;  // log2n = 0 marks a slot without a block
-            blk_s[wv][2] = use_flt ? 1u : 0u;
+            blk_s[wv][2] = w3;
             blk_s[wv][3] = (unsigned)dcv;
           }
         } else {
-          hr_wave_sync();  // the smoothed samples were written by other lanes of this wave
+          hr_wave_sync();  // the reference samples were written by other lanes of this wave
           if (in_range)
-            intra_predict(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, use_flt ? flt : ref, dcv, lane, 64);
+            intra_predict(intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[wv]), lane, 64);
         }
       }
+      HR_STAMP(9)
       if (two_phase) {
       __syncthreads();
+      HR_STAMP(10)
       // ---- phase B: prediction + residual + store (TLibCommon/TComPrediction.cpp:183-390,691-763), all waves
       //      over all blocks of the round, 64 samples at a time
       // Lane b < nb fetches block b's slot; a block of npx samples is max(1, npx / 64) chunks, chunk g of the round
@@ -1683,10 +1726,8 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
       // walking the slots one dependent LDS read after the other.
       unsigned my0 = 0, my1 = 0, my2 = 0, my3 = 0;
       if (lane < nb) {
-        my0 = blk_s[lane][0];
-        my1 = blk_s[lane][1];
-        my2 = blk_s[lane][2];
-        my3 = blk_s[lane][3];
+        const uint4 q = *(const uint4 *)blk_s[lane];
+        my0 = q.x, my1 = q.y, my2 = q.z, my3 = q.w;
       }
       const int my_log2n = my1 & 255;
       const unsigned long long below = (1ull << lane) - 1;
@@ -1697,17 +1738,19 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
       while (mine) {
         const int b = __ffsll((long long)mine) - 1;
         mine &= mine - 1;
-        const unsigned w0 = (unsigned)hr_readlane((int)my0, b), w1 = (unsigned)hr_readlane((int)my1, b);
+        const unsigned w0 = (unsigned)hr_readlane((int)my0, b), w1 = (unsigned)hr_readlane((int)my1, b), w3 = (unsigned)hr_readlane((int)my2, b);
         const int c0 = (wv - hr_readlane(my_chunk0, b)) & (IT_WAVES - 1);
-        const bool use_flt = hr_readlane((int)my2, b) != 0;
         const int dcv = hr_readlane((int)my3, b);
-        intra_predict(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, (use_flt ? flt_s[b] : ref_s[b]), dcv,
+        intra_predict(intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[b]),
                       c0 * 64 + lane, IT_WAVES * 64);
       }
       }
+      HR_STAMP(11)
       __syncthreads();  // the next round reads what this one wrote into the tile and reuses the block slots
-    }
-    base += cnt;
+      HR_STAMP(12)
+#ifdef HEVCRECON_INTRA_STAMPS
+      if (tid == 0) acc_[7] += 1, acc_[13] += two_phase ? 1 : 0;
+#endif
   }
   HR_STAMP(3)
   // ---- write the CTU back (in P/B pictures the inter samples staged above go back unchanged) ----
@@ -1744,9 +1787,15 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
   if (tid == 0) hr_flag_raise(J.ctu_done + (size_t)ci.cy * s.ctus_w + ci.cx);
   HR_STAMP(5)
 #ifdef HEVCRECON_INTRA_STAMPS
-  if (tid == 0) atomicAdd(&hr_intra_stamps[6], 1ull);
+  if (tid == 0) acc_[6] += 1;
 #endif
   }  // next CTU
+#ifdef HEVCRECON_INTRA_STAMPS
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) atomicAdd(&hr_intra_stamps[k], acc_[k]);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

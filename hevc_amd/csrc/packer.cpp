@@ -51,6 +51,7 @@ void PackedPicture::begin(const SeqInfo &s) {
   ictu.clear();
   ictu_wave.clear();
   lvl_counts.clear();
+  rounds.clear();
   wave_off.clear();
   ctu_wave.assign((size_t)s.ctus_w * s.ctus_h, 0);
   sao.assign((size_t)s.ctus_w * s.ctus_h * 3, SaoCtu());
@@ -240,8 +241,10 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
     ic.cy = (uint8_t)cy;
     ic.deps = (uint8_t)ctu_dep_mask;
     ic.pad = 0;
+    ic.pad2 = 0;
     for (int l = 1; l <= nlev; l++) lvl_counts.push_back((uint16_t)start[l + 1]);
     for (int l = 1; l <= nlev + 1; l++) start[l] += start[l - 1];
+    const std::vector<int> first(start);  // first[l] = first block of level l, relative to the CTU's first
     intra.resize(ic.item_start + ctu_items.size());
     intra_nb.resize(intra.size());
     for (size_t i = 0; i < ctu_items.size(); i++) {
@@ -249,6 +252,20 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
       intra[at] = ctu_items[i];
       intra_nb[at] = ctu_item_nb[i];
     }
+    // rounds: the blocks of a level, HR_INTRA_ROUND_BLOCKS at a time
+    ic.round_start = (uint32_t)rounds.size();
+    for (int l = 1; l <= nlev; l++)
+      for (int b = first[l]; b < first[l + 1]; b += HR_INTRA_ROUND_BLOCKS) {
+        const int nb = std::min<int>(HR_INTRA_ROUND_BLOCKS, first[l + 1] - b);
+        bool big = false;
+        for (int k = 0; k < nb; k++) big = big || intra[ic.item_start + b + k].log2n == 5;
+        rounds.push_back((uint16_t)(b | (nb << IR_COUNT_SHIFT) | (big ? IR_BIG : 0)));
+      }
+    if (rounds.size() - ic.round_start > HR_INTRA_MAX_ROUNDS) {
+      error = "CTU holds more intra blocks or dependency levels than a 64x64 CTU can";
+      return false;
+    }
+    ic.n_rounds = (uint16_t)(rounds.size() - ic.round_start);
     // wave: after every neighbouring CTU whose intra blocks this CTU's blocks actually read (found while the
     // blocks' neighbour masks were built)
     const int wave = ctu_dep_wave;
@@ -493,12 +510,10 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
   it.flags = (uint8_t)(corner ? IN_CORNER : 0);
   it.avail_left = left;
   it.avail_above = above;
-  it.resi_off = 0;
+  it.prep = 0;
   if ((ctu->cbf[comp][z] >> ctu->tr_idx[z]) & 1) {
-    uint32_t off = 0;
-    emit_tu(ctu, comp, z, zcu, x, y, log2n, TU_TO_RESI | ((comp == 0 && log2n == 2) ? TU_DST : 0), &off);
+    emit_tu(ctu, comp, z, zcu, x, y, log2n, TU_TO_RESI | ((comp == 0 && log2n == 2) ? TU_DST : 0), NULL);
     it.flags |= IN_HAS_RESI;
-    it.resi_off = off;
   }
   ctu_items.push_back(it);
   ctu_item_nb.push_back(nb);
@@ -532,6 +547,40 @@ void PackedPicture::intra_tus(const hevcrecon_ctu_syntax *ctu, int ctux, int ctu
   emit_intra(ctu, 2, z, zcu, x >> 1, y >> 1, clog2, mode);
 }
 
+// What the intra kernel would otherwise derive per block from the item's other fields (IP_*).
+uint32_t PackedPicture::intra_prep(const IntraItem &it) {
+  const int n = 1 << it.log2n, us = it.comp ? 2 : 4, nu = n / us;
+  // availability of the 4*nu + 1 units in sample order: left column bottom-up, corner, row above left to right
+  uint64_t m = 0;
+  for (int u = 0; u < 2 * nu; u++)
+    if ((it.avail_left >> (2 * nu - 1 - u)) & 1) m |= 1ull << u;
+  if (it.flags & IN_CORNER) m |= 1ull << (2 * nu);
+  for (int u = 0; u < 2 * nu; u++)
+    if ((it.avail_above >> u) & 1) m |= 1ull << (2 * nu + 1 + u);
+  auto first_of = [&](int u) { return u < 2 * nu ? u * us : u == 2 * nu ? 2 * n : 2 * n + 1 + (u - 2 * nu - 1) * us; };
+  auto last_of = [&](int u) { return u < 2 * nu ? u * us + us - 1 : u == 2 * nu ? 2 * n : 2 * n + 1 + (u - 2 * nu - 1) * us + us - 1; };
+  uint32_t prep = 0;
+  if (m) {
+    const int ua = __builtin_ctzll(m), ub = 63 - __builtin_clzll(m);
+    const bool run = (m >> ua) == (ub - ua == 63 ? ~0ull : (1ull << (ub - ua + 1)) - 1);
+    prep |= (uint32_t)first_of(ua) << IP_FIRST_SHIFT | (uint32_t)last_of(ub) << IP_LAST_SHIFT |
+            (uint32_t)(run ? IP_KIND_RUN : IP_KIND_HOLES) << IP_KIND_SHIFT;
+  }
+  // smoothing of the reference samples (TComPattern::getPredictorPtr, TLibCommon/TComPattern.cpp:627-651): luma only,
+  // not for DC, by the distance of the mode from pure horizontal / vertical
+  const int dist = std::min(std::abs(it.mode - 10), std::abs(it.mode - 26));
+  const int thr = it.log2n == 2 ? 10 : it.log2n == 3 ? 7 : it.log2n == 4 ? 1 : 0;
+  if (it.comp == 0 && it.mode != 1 && dist > thr) prep |= IP_FILTER;
+  if (it.mode >= 2) {
+    // intraPredAngle (TLibCommon/TComPrediction.cpp:211-230): horizontal modes mirror the vertical ones
+    static const int kAngle[9] = {0, 2, 5, 9, 13, 17, 21, 26, 32};
+    const bool hor = it.mode < 18;
+    const int a = hor ? -(it.mode - 10) : it.mode - 26, aa = std::abs(a);
+    prep |= (uint32_t)((a < 0 ? -kAngle[aa] : kAngle[aa]) + 32) << IP_ANGLE_SHIFT | (uint32_t)aa << IP_ABS_SHIFT;
+  }
+  return prep;
+}
+
 bool PackedPicture::finish(const hevcrecon_pic_params *p) {
   if (!error.empty()) return false;
   if (next_ctu != seq.ctus_w * seq.ctus_h) {
@@ -553,6 +602,7 @@ bool PackedPicture::finish(const hevcrecon_pic_params *p) {
       intra[i].avail_above &= intra_nb[i].above;
       if (!intra_nb[i].corner) intra[i].flags &= (uint8_t)~IN_CORNER;
     }
+  for (size_t i = 0; i < intra.size(); i++) intra[i].prep = intra_prep(intra[i]);
   // order the CTUs that hold intra blocks by wave
   int nw = 0;
   for (size_t i = 0; i < ictu_wave.size(); i++) nw = std::max<int>(nw, ictu_wave[i]);

@@ -22,7 +22,8 @@ struct PackedPicture {
   template <typename T> uint32_t append_block(const T *src, int nn);
   std::vector<IntraItem> intra;     // grouped by CTU, by local level inside a CTU
   std::vector<IntraCtu> ictu;       // CTUs holding intra blocks, sorted by wave after finish()
-  std::vector<uint16_t> lvl_counts; // per CTU, per local level: number of blocks
+  std::vector<uint16_t> lvl_counts; // per CTU, per local level: number of blocks (host only: statistics)
+  std::vector<uint16_t> rounds;     // per CTU: the rounds the intra kernel takes its blocks in (IR_*)
   std::vector<int32_t> wave_off;    // n_waves + 1 offsets into ictu
   std::vector<SaoCtu> sao;
   // Slices that differ in their parameters or are not filtered across (set before the first CTU; empty: the picture
@@ -82,6 +83,7 @@ struct PackedPicture {
   void intra_tus(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy, int zcu, int z, int size, int trdepth, int chroma);
   void emit_tu(const hevcrecon_ctu_syntax *ctu, int comp, int z, int zcu, int x, int y, int log2n, int flags, uint32_t *off_out);
   void emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z, int zcu, int x, int y, int log2n, int mode);
+  static uint32_t intra_prep(const IntraItem &it);
   int coding_order(int ux, int uy) const;
   const hevcrecon_slice_params *slice_at(uint32_t start) const;
   bool build_ctu_info();
