@@ -1235,8 +1235,10 @@ __device__ __forceinline__ int hr_wave_sum(int v) {
 
 #define IT_WAVES HR_INTRA_ROUND_BLOCKS /* waves per workgroup (power of two) = blocks per round */
 #define IT_NTHR (IT_WAVES * 64)
-#define IT_YW 100 /* luma tile row: x = -1 .. 96 (97 used) */
-#define IT_CW 52  /* chroma tile row: x = -1 .. 48 (49 used) */
+#define IT_X0 4   /* tile column of the CTU's first sample: the column left of it holds the left neighbours, and
+                     groups of four samples start on 8-byte boundaries */
+#define IT_YW 100 /* luma tile row: x = -1 .. 95 in columns 3 .. 99 */
+#define IT_CW 52  /* chroma tile row: x = -1 .. 47 in columns 3 .. 51 */
 #define IT_REFW 136 /* reference samples of a block: 4 * 32 + 1, rounded up */
 
 // invAngle by |mode - 26| (or |mode - 10|), TLibCommon/TComPrediction.cpp:226-230
@@ -1369,9 +1371,9 @@ __device__ __forceinline__ IntraBlk intra_blk(const SeqInfo &s, uint16_t *tile_y
   B.maxv = (1 << (comp ? s.bd_c : s.bd_y)) - 1;
   B.tw = comp ? IT_CW : IT_YW;
   B.rw = comp ? 32 : 64;
-  const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
+  const int tx0 = x0 - (ctux >> sh) + IT_X0, ty0 = y0 - (ctuy >> sh) + 1;
   B.tile0 = (comp == 0 ? tile_y : comp == 1 ? tile_cb : tile_cr) + ty0 * B.tw + tx0;
-  B.resi0 = (comp == 0 ? resi_y : comp == 1 ? resi_cb : resi_cr) + (ty0 - 1) * B.rw + tx0 - 1;
+  B.resi0 = (comp == 0 ? resi_y : comp == 1 ? resi_cb : resi_cr) + (ty0 - 1) * B.rw + tx0 - IT_X0;
   B.cn = refs + 2 * n;
   B.edge = comp == 0 && n <= 16;
   B.has_resi = (flags & IN_HAS_RESI) != 0;
@@ -1381,72 +1383,83 @@ __device__ __forceinline__ IntraBlk intra_blk(const SeqInfo &s, uint16_t *tile_y
   return B;
 }
 
-// Angular prediction of one sample from main-reference index i0 (>= 0 for positive angles) and fraction df.
-// (df = 0 gives a0 exactly, so the interpolation needs no special case.)
-__device__ __forceinline__ int intra_ang_pos(const uint16_t *cn, int sgn, int i0, int df) {
-  const int a0 = cn[sgn * i0], a1 = cn[sgn * (i0 + 1)];
-  return (__mul24(32 - df, a0) + __mul24(df, a1) + 16) >> 5;
-}
-__device__ __forceinline__ int intra_ang_neg(const uint16_t *cn, int sgn, int inv, int i0, int df) {
-  const int i1 = i0 + 1;
-  const int a0 = i0 >= 0 ? cn[sgn * i0] : cn[-sgn * ((128 - __mul24(i0, inv)) >> 8)];
-  const int a1 = i1 >= 0 ? cn[sgn * i1] : cn[-sgn * ((128 - __mul24(i1, inv)) >> 8)];
-  return (__mul24(32 - df, a0) + __mul24(df, a1) + 16) >> 5;
-}
-
-// Prediction + residual + clip of the samples p_first, p_first + p_step, ... (raster inside the block) of one intra block,
-// written into the CTU tile (TLibCommon/TComPrediction.cpp:183-390,691-763).
-__device__ __forceinline__ void intra_predict(const IntraBlk &B, int p_first, int p_step) {
-    const int log2n = B.log2n, n = 1 << log2n, npx = n * n;
-    const int mode = B.mode, maxv = B.maxv, tw = B.tw, rw = B.rw, dcv = B.dcv;
-    const uint16_t *cn = B.cn;
-    const int16_t *resi0 = B.resi0;
-    uint16_t *tile0 = B.tile0;
-    const bool has_resi = B.has_resi, edge = B.edge;
-#define INTRA_STORE_LOOP(EXPR)                                       \
-  for (int p = p_first; p < npx; p += p_step) {                      \
-const int py = p >> log2n, px = p & (n - 1);                     \
-int v = (EXPR);                                                  \
-if (has_resi) v += resi0[py * rw + px];                          \
-tile0[py * tw + px] = (uint16_t)clip3i(0, maxv, v);              \
-  }
-    if (mode == 0) {  // planar
-      const int tr = cn[1 + n], bl = cn[-1 - n];
-      INTRA_STORE_LOOP(((cn[-1 - py] << log2n) + n + __mul24(px + 1, tr - cn[-1 - py]) + (cn[1 + px] << log2n) + __mul24(py + 1, bl - cn[1 + px])) >> (log2n + 1))
-    } else if (mode == 1) {  // DC
-      if (edge) {
-        INTRA_STORE_LOOP((px == 0 && py == 0) ? (cn[1] + cn[-1] + 2 * dcv + 2) >> 2
-                         : py == 0            ? (cn[1 + px] + 3 * dcv + 2) >> 2
-                         : px == 0            ? (cn[-1 - py] + 3 * dcv + 2) >> 2
-                                              : dcv)
-      } else {
-        INTRA_STORE_LOOP(dcv)
+// Prediction + residual + clip of one intra block, written into the CTU tile (TLibCommon/TComPrediction.cpp:183-390,
+// 691-763).  The block is cut into groups of four samples that lie side by side ACROSS the prediction direction (in
+// a row for planar, DC and the vertical modes; in a column for the horizontal modes, which are the vertical ones on
+// the transposed block: sgn flips the index direction of the reference array).  The four samples of a group share
+// their position along the direction -- so the angular modes' reference offset and fraction -- and read five
+// neighbouring reference samples; row groups load their residual and store their result as 8 bytes.  This call
+// handles groups g_first, g_first + g_step, ...
+__device__ __forceinline__ void intra_predict(const IntraBlk &B, int g_first, int g_step) {
+  const int log2n = B.log2n, n = 1 << log2n, ngr = (n * n) >> 2;
+  const int mode = B.mode, maxv = B.maxv, tw = B.tw, rw = B.rw, dcv = B.dcv;
+  const uint16_t *cn = B.cn;
+  const bool hor = mode >= 2 && mode < 18;
+  const int sgn = hor ? -1 : 1;  // MAIN(i) = cn[sgn * i], SIDE(i) = cn[-sgn * i]
+  const int angle = B.angle, inv = B.inv;
+  for (int g = g_first; g < ngr; g += g_step) {
+    const int kk = g >> (log2n - 2);              // position along the prediction direction
+    const int ee = (g & ((n >> 2) - 1)) << 2;     // first of the four positions across it
+    int v[4];
+    if (mode == 0) {  // planar: kk = row, ee = column
+      const int left = cn[-1 - kk], tr = cn[1 + n], bl = cn[-1 - n];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int top = cn[1 + ee + e];
+        v[e] = ((left << log2n) + n + __mul24(ee + e + 1, tr - left) + (top << log2n) + __mul24(kk + 1, bl - top)) >> (log2n + 1);
       }
-    } else {
-      // angular: vertical modes predict from the row above, horizontal modes are the same computation
-      // on the transposed block (main = left column): sgn flips the index direction
-      const bool hor = mode < 18;
-      const int angle = B.angle, inv = B.inv;
-      const int sgn = hor ? -1 : 1;  // MAIN(i) = cn[sgn * i], SIDE(i) = cn[-sgn * i]
-#define KK (hor ? px : py) /* index along the prediction direction */
-#define EE (hor ? py : px) /* index across it */
-      if (angle == 0) {
-        if (edge) {
-          const int side0 = cn[0];
-          INTRA_STORE_LOOP(EE == 0 ? clip3i(0, maxv, cn[sgn] + ((cn[-sgn * (KK + 1)] - side0) >> 1)) : cn[sgn * (EE + 1)])
-        } else {
-          INTRA_STORE_LOOP(cn[sgn * (EE + 1)])
+    } else if (mode == 1) {  // DC, with its edge smoothing for luma blocks up to 16x16
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = dcv;
+      if (B.edge) {
+        if (kk == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = (cn[1 + ee + e] + 3 * dcv + 2) >> 2;
+          if (ee == 0) v[0] = (cn[1] + cn[-1] + 2 * dcv + 2) >> 2;
+        } else if (ee == 0) {
+          v[0] = (cn[-1 - kk] + 3 * dcv + 2) >> 2;
         }
-      } else if (angle > 0) {
-        INTRA_STORE_LOOP(intra_ang_pos(cn, sgn, EE + 1 + (__mul24(KK + 1, angle) >> 5), __mul24(KK + 1, angle) & 31))
+      }
+    } else if (angle == 0) {  // pure vertical / horizontal
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = cn[sgn * (ee + e + 1)];
+      if (B.edge && ee == 0) v[0] = clip3i(0, maxv, cn[sgn] + ((cn[-sgn * (kk + 1)] - cn[0]) >> 1));
+    } else {
+      const int t = __mul24(kk + 1, angle), i0 = ee + 1 + (t >> 5), f = t & 31;
+      int m[5];
+      if (angle > 0) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) m[j] = cn[sgn * (i0 + j)];
       } else {
         // negative indices address the side reference projected onto the main one
-        INTRA_STORE_LOOP(intra_ang_neg(cn, sgn, inv, EE + 1 + (__mul24(KK + 1, angle) >> 5), __mul24(KK + 1, angle) & 31))
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          const int idx = i0 + j;
+          m[j] = cn[idx >= 0 ? sgn * idx : -sgn * ((128 - __mul24(idx, inv)) >> 8)];
+        }
       }
-#undef KK
-#undef EE
+      // (f = 0 gives m[e] exactly, so the interpolation needs no special case)
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = (__mul24(32 - f, m[e]) + __mul24(f, m[e + 1]) + 16) >> 5;
     }
-#undef INTRA_STORE_LOOP
+    if (!hor) {
+      const int at = __mul24(kk, tw) + ee;
+      if (B.has_resi) {
+        const uint2 r = *(const uint2 *)(B.resi0 + __mul24(kk, rw) + ee);
+        v[0] += (int)(int16_t)(r.x & 0xffffu), v[1] += (int)r.x >> 16, v[2] += (int)(int16_t)(r.y & 0xffffu), v[3] += (int)r.y >> 16;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) v[e] = clip3i(0, maxv, v[e]);
+      *(uint2 *)(B.tile0 + at) = make_uint2((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        int x = v[e];
+        if (B.has_resi) x += B.resi0[__mul24(ee + e, rw) + kk];
+        B.tile0[__mul24(ee + e, tw) + kk] = (uint16_t)clip3i(0, maxv, x);
+      }
+    }
+  }
 }
 
 // The 32x32 blocks have a launch of their own (33 KB of LDS and 103 registers per lane would cost the small blocks
@@ -1511,10 +1524,10 @@ void hr_intra_stamps_report() {
 
 template <typename pel_t>
 __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s, const unsigned *list, int n_items, unsigned *ticket) {
-  __shared__ uint16_t tile_y[65 * IT_YW];
-  __shared__ uint16_t tile_c[2][33 * IT_CW];
-  __shared__ int16_t resi_y[64 * 64];
-  __shared__ int16_t resi_c[2][32 * 32];
+  __shared__ __attribute__((aligned(16))) uint16_t tile_y[65 * IT_YW];
+  __shared__ __attribute__((aligned(16))) uint16_t tile_c[2][33 * IT_CW];
+  __shared__ __attribute__((aligned(16))) int16_t resi_y[64 * 64];
+  __shared__ __attribute__((aligned(16))) int16_t resi_c[2][32 * 32];
   __shared__ __attribute__((aligned(16))) IntraItem items_s[IT_MAX_ITEMS];
   __shared__ uint16_t rounds_s[IT_MAX_ROUNDS];
   __shared__ uint16_t ref_s[IT_WAVES][IT_REFW];
@@ -1619,7 +1632,7 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
         if (v < 64 * VPR_Y && gx < s.w && gy < s.h) {
           const uint4 q = *(const uint4 *)(py + (size_t)gy * s.stride_y + gx);
           const unsigned w[4] = {q.x, q.y, q.z, q.w};
-          uint16_t *t = &tile_y[(ty + 1) * IT_YW + tx + 1];
+          uint16_t *t = &tile_y[(ty + 1) * IT_YW + tx + IT_X0];
 #pragma unroll
           for (int e = 0; e < SPV; e++)
             t[e] = sizeof(pel_t) == 1 ? (uint16_t)((w[e >> 2] >> (8 * (e & 3))) & 255) : (uint16_t)((w[e >> 1] >> (16 * (e & 1))) & 65535);
@@ -1635,7 +1648,7 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
           if (gx < s.cw && gy < s.ch) {
             const uint4 q = *(const uint4 *)((const pel_t *)J.rec[1 + c] + (size_t)gy * s.stride_c + gx);
             const unsigned w[4] = {q.x, q.y, q.z, q.w};
-            uint16_t *t = &tile_c[c][(ty + 1) * IT_CW + tx + 1];
+            uint16_t *t = &tile_c[c][(ty + 1) * IT_CW + tx + IT_X0];
 #pragma unroll
             for (int e = 0; e < SPV; e++)
               t[e] = sizeof(pel_t) == 1 ? (uint16_t)((w[e >> 2] >> (8 * (e & 3))) & 255) : (uint16_t)((w[e >> 1] >> (16 * (e & 1))) & 65535);
@@ -1649,23 +1662,23 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
       const pel_t *py = (const pel_t *)J.rec[0];
       if (tid < 97) {
         const int gx = ctux + tid - 1, gy = ctuy - 1;
-        if (gx >= 0 && gy >= 0 && gx < s.w) tile_y[tid] = py[(size_t)gy * s.stride_y + gx];
+        if (gx >= 0 && gy >= 0 && gx < s.w) tile_y[tid + IT_X0 - 1] = py[(size_t)gy * s.stride_y + gx];
       }
       if (tid >= 128 && tid < 192) {
         const int gx = ctux - 1, gy = ctuy + tid - 128;
-        if (gx >= 0 && gy < s.h) tile_y[(tid - 128 + 1) * IT_YW] = py[(size_t)gy * s.stride_y + gx];
+        if (gx >= 0 && gy < s.h) tile_y[(tid - 128 + 1) * IT_YW + IT_X0 - 1] = py[(size_t)gy * s.stride_y + gx];
       }
       {
         const int c = tid >> 6, i = tid & 63;
         if (c < 2 && i < 49) {
           const int gx = (ctux >> 1) + i - 1, gy = (ctuy >> 1) - 1;
-          if (gx >= 0 && gy >= 0 && gx < s.cw) tile_c[c][i] = ((const pel_t *)J.rec[1 + c])[(size_t)gy * s.stride_c + gx];
+          if (gx >= 0 && gy >= 0 && gx < s.cw) tile_c[c][i + IT_X0 - 1] = ((const pel_t *)J.rec[1 + c])[(size_t)gy * s.stride_c + gx];
         }
       }
       if (tid >= 192 && tid < 256) {
         const int c = (tid - 192) >> 5, j = (tid - 192) & 31;
         const int gx = (ctux >> 1) - 1, gy = (ctuy >> 1) + j;
-        if (gx >= 0 && gy < s.ch) tile_c[c][(j + 1) * IT_CW] = ((const pel_t *)J.rec[1 + c])[(size_t)gy * s.stride_c + gx];
+        if (gx >= 0 && gy < s.ch) tile_c[c][(j + 1) * IT_CW + IT_X0 - 1] = ((const pel_t *)J.rec[1 + c])[(size_t)gy * s.stride_c + gx];
       }
     }
     // residual of the CTU's coded intra blocks (positions without one hold garbage and are never read), block list
@@ -1699,7 +1712,7 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
         const int sh = comp ? 1 : 0;
         const int tw = comp ? IT_CW : IT_YW;
         // position of the block inside the tile (tile index 0 = sample -1 of the CTU)
-        const int tx0 = x0 - (ctux >> sh) + 1, ty0 = y0 - (ctuy >> sh) + 1;
+        const int tx0 = x0 - (ctux >> sh) + IT_X0, ty0 = y0 - (ctuy >> sh) + 1;
         const int dcv = intra_references(comp ? tile_c[comp - 1] : tile_y, tw, (ty0 - 1) * tw + tx0 - 1, log2n, comp, mode, flags, w2, w3,
                                          comp ? s.bd_c : s.bd_y, s.strong_intra, ref_s[wv], lane);
         if (two_phase) {
@@ -1720,9 +1733,9 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
       __syncthreads();
       HR_STAMP(10)
       // ---- phase B: prediction + residual + store (TLibCommon/TComPrediction.cpp:183-390,691-763), all waves
-      //      over all blocks of the round, 64 samples at a time
-      // Lane b < nb fetches block b's slot; a block of npx samples is max(1, npx / 64) chunks, chunk g of the round
-      // belongs to wave g % IT_WAVES.  Every wave finds the blocks it has a chunk of with three ballots instead of
+      //      over all blocks of the round, 64 groups of four samples at a time
+      // Lane b < nb fetches block b's slot; a block is cut into chunks of 64 groups of four samples (a 32x32 block into
+      // four, smaller ones are one chunk), chunk g of the round belongs to wave g % IT_WAVES.  Every wave finds the blocks it has a chunk of with three ballots instead of
       // walking the slots one dependent LDS read after the other.
       unsigned my0 = 0, my1 = 0, my2 = 0, my3 = 0;
       if (lane < nb) {
@@ -1731,9 +1744,8 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
       }
       const int my_log2n = my1 & 255;
       const unsigned long long below = (1ull << lane) - 1;
-      const int my_chunk0 = 16 * __popcll(__ballot(my_log2n == 5) & below) + 4 * __popcll(__ballot(my_log2n == 4) & below) +
-                            __popcll(__ballot(my_log2n == 2 || my_log2n == 3) & below);
-      const int my_nch = my_log2n == 5 ? 16 : my_log2n == 4 ? 4 : 1;
+      const int my_chunk0 = 4 * __popcll(__ballot(my_log2n == 5) & below) + __popcll(__ballot(my_log2n >= 2 && my_log2n <= 4) & below);
+      const int my_nch = my_log2n == 5 ? 4 : 1;
       unsigned long long mine = __ballot(my_log2n != 0 && ((wv - my_chunk0) & (IT_WAVES - 1)) < my_nch);
       while (mine) {
         const int b = __ffsll((long long)mine) - 1;
@@ -1769,7 +1781,7 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
     for (int i = tid; i < 64 * 64 / SPS; i += IT_NTHR) {
       const int ty = i / (64 / SPS), tx = (i % (64 / SPS)) * SPS;
       const int gx = ctux + tx, gy = ctuy + ty;
-      if (gx < s.w && gy < s.h) hr_store_through((unsigned long long *)(py + (size_t)gy * s.stride_y + gx), pack8(&tile_y[(ty + 1) * IT_YW + tx + 1]));
+      if (gx < s.w && gy < s.h) hr_store_through((unsigned long long *)(py + (size_t)gy * s.stride_y + gx), pack8(&tile_y[(ty + 1) * IT_YW + tx + IT_X0]));
     }
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -1777,7 +1789,7 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
       for (int i = tid; i < 32 * 32 / SPS; i += IT_NTHR) {
         const int ty = i / (32 / SPS), tx = (i % (32 / SPS)) * SPS;
         const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
-        if (gx < s.cw && gy < s.ch) hr_store_through((unsigned long long *)(pc + (size_t)gy * s.stride_c + gx), pack8(&tile_c[c][(ty + 1) * IT_CW + tx + 1]));
+        if (gx < s.cw && gy < s.ch) hr_store_through((unsigned long long *)(pc + (size_t)gy * s.stride_c + gx), pack8(&tile_c[c][(ty + 1) * IT_CW + tx + IT_X0]));
       }
     }
   }
