@@ -1053,7 +1053,9 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
   if (n_intra_ctus > 0) {
     HIPCHK(c, hipMemsetAsync(ws.sync_dev, 0, (kSyncHead + (size_t)n * s.ctus_w * s.ctus_h) * sizeof(uint32_t), c->stream));
     Timed tm(c, K_INTRA, 1, !ws.fixed);
-    hr_launch_intra(jd, s, intra_list, (int)n_intra_ctus, intra_parallel, ws.sync_dev, c->stream);
+    // "dense": pictures coded mostly in intra blocks, and enough of them to keep more workgroups busy
+    const bool dense = n >= 8 && n_intra_ctus * 4 >= (size_t)n * s.ctus_w * s.ctus_h * 3;
+    hr_launch_intra(jd, s, intra_list, (int)n_intra_ctus, intra_parallel, dense, ws.sync_dev, c->stream);
   }
   if (stages) {
     Timed tm(c, K_COPY, 1);

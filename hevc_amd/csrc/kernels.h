@@ -13,8 +13,9 @@ void hr_launch(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_
 // index into that picture's ictu[]) in an order in which every CTU follows the CTUs it reads from, or is NULL for
 // a single picture (its ictu[] is in such an order already).  `ticket` and every picture's ctu_done words must be
 // zero when the kernel starts.
-// max_parallel: the most CTUs that can be in work at a time (the batch's largest wave).
-void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list, int n_items, int max_parallel, unsigned *ticket,
+// max_parallel: the most CTUs that can be in work at a time (the batch's largest wave); dense: the batch's pictures are
+// coded mostly in intra blocks (the launch then gets more workgroups).
+void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list, int n_items, int max_parallel, bool dense, unsigned *ticket,
                      hipStream_t stream);
 
 // Converts picture planes to the bytes TVideoIOYuv::write puts into a file: width x height samples of each plane

@@ -1243,6 +1243,7 @@ __device__ __forceinline__ int hr_wave_sum(int v) {
 
 // invAngle by |mode - 26| (or |mode - 10|), TLibCommon/TComPrediction.cpp:226-230
 __constant__ int kIntraInvAngle[16] = {0, 4096, 1638, 910, 630, 482, 390, 315, 256, 0, 0, 0, 0, 0, 0, 0};
+// (the kernel keeps the table in one register, entry i in lane i, and picks from it with a lane read)
 
 // One wave builds the reference samples r[0 .. 4n] of a block (r[2n] is the corner, r[2n-1-j] the left column going
 // down, r[2n+1+i] the row above going right: TComPattern::initAdiPattern / fillReferenceSamples,
@@ -1360,7 +1361,7 @@ struct IntraBlk {
 };
 __device__ __forceinline__ IntraBlk intra_blk(const SeqInfo &s, uint16_t *tile_y, uint16_t *tile_cb, uint16_t *tile_cr, const int16_t *resi_y,
                                               const int16_t *resi_cb, const int16_t *resi_cr, int ctux, int ctuy, unsigned w0, unsigned w1,
-                                              unsigned w3, int dcv, const uint16_t *refs) {
+                                              unsigned w3, int dcv, const uint16_t *refs, int inv_tab) {
   IntraBlk B;
   B.log2n = w1 & 255;
   const int n = 1 << B.log2n;
@@ -1378,7 +1379,7 @@ __device__ __forceinline__ IntraBlk intra_blk(const SeqInfo &s, uint16_t *tile_y
   B.edge = comp == 0 && n <= 16;
   B.has_resi = (flags & IN_HAS_RESI) != 0;
   B.angle = (int)((w3 >> IP_ANGLE_SHIFT) & 127) - 32;
-  B.inv = kIntraInvAngle[(w3 >> IP_ABS_SHIFT) & 15];
+  B.inv = hr_readlane(inv_tab, (int)((w3 >> IP_ABS_SHIFT) & 15));
   B.dcv = dcv;
   return B;
 }
@@ -1523,7 +1524,10 @@ void hr_intra_stamps_report() {
 #endif
 
 template <typename pel_t>
-__global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s, const unsigned *list, int n_items, unsigned *ticket) {
+#ifndef HEVCRECON_INTRA_MIN_WAVES
+#define HEVCRECON_INTRA_MIN_WAVES 6 /* waves per SIMD that the register allocation leaves room for: three workgroups per compute unit */
+#endif
+__global__ __launch_bounds__(IT_NTHR, HEVCRECON_INTRA_MIN_WAVES) void k_intra(const PicJob *jobs, SeqInfo s, const unsigned *list, int n_items, unsigned *ticket) {
   __shared__ __attribute__((aligned(16))) uint16_t tile_y[65 * IT_YW];
   __shared__ __attribute__((aligned(16))) uint16_t tile_c[2][33 * IT_CW];
   __shared__ __attribute__((aligned(16))) int16_t resi_y[64 * 64];
@@ -1534,6 +1538,7 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
   __shared__ __attribute__((aligned(16))) unsigned blk_s[IT_WAVES][4];  // per block of a two-phase round: item words 0, 1 and 3, DC value
   __shared__ unsigned ticket_s;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  const int inv_tab = kIntraInvAngle[lane & 15];
   // One launch per batch.  The batch's CTUs (those holding intra blocks) stand in a list ordered so that every CTU
   // comes after the CTUs it reads from (all pictures' first waves, then their second waves, ...; for a single
   // picture the order of its own table, list = NULL).  Workgroups draw the next entry until the list is exhausted
@@ -1692,20 +1697,30 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
   HR_STAMP(2)
 
   const int n_rounds = ci.n_rounds < IT_MAX_ROUNDS ? ci.n_rounds : IT_MAX_ROUNDS;
+  // A round's description and the block each wave takes in it are fetched one round ahead (the reads are issued
+  // before the barrier that ends the round before, and used after it).
+  unsigned rword = n_rounds > 0 ? hr_uniform((unsigned)rounds_s[0]) : 0u;
+  uint4 q = make_uint4(0, 0, 0, 0);
+  {
+    const int b0 = (int)(rword & IR_BASE_MASK) + wv;
+    if (wv < (int)((rword >> IR_COUNT_SHIFT) & IR_COUNT_MASK)) q = *(const uint4 *)&items_s[b0 < nit ? b0 : 0];
+  }
   for (int r = 0; r < n_rounds; r++) {
       // The round: its first block, how many, and whether a 32x32 block is among them (the packer's table).
       // A round without a 32x32 block is finished by the waves that build the references: each predicts its own
-      // block (at most four passes of 64 samples) and the round costs one barrier.  The 16 passes of a 32x32 block
-      // are worth spreading over all waves, at the price of a hand-over through LDS and a second barrier.
-      const unsigned rword = hr_uniform((unsigned)rounds_s[r]);
+      // block in one pass and the round costs one barrier.  The four passes of a 32x32 block are worth spreading
+      // over the waves, at the price of a hand-over through LDS and a second barrier.
       const int rbase = rword & IR_BASE_MASK, nb = min((int)((rword >> IR_COUNT_SHIFT) & IR_COUNT_MASK), IT_WAVES);
       const bool two_phase = (rword & IR_BIG) != 0;
+      const unsigned rword_next_v = rounds_s[r + 1 < n_rounds ? r + 1 : r];
       HR_STAMP(8)
-      // ---- phase A: wave b builds the reference samples of block b ----
-      if (wv < nb) {
-        const bool in_range = rbase + wv < nit;
+      // ---- phase A: one wave per block builds its reference samples ----
+      // (which wave takes which block rotates from round to round: workgroups that share a compute unit then spread
+      // their busy waves over its four SIMDs instead of all loading the first ones)
+      const int slot = (wv + 3 * r) & (IT_WAVES - 1);
+      if (slot < nb) {
+        const bool in_range = rbase + slot < nit;
         // The block's description is the same in every lane: keep it in scalar registers.
-        const uint4 q = *(const uint4 *)&items_s[in_range ? rbase + wv : 0];
         const unsigned w0 = hr_uniform(q.x), w1 = hr_uniform(q.y), w2 = hr_uniform(q.z), w3 = hr_uniform(q.w);
         const int x0 = w0 & 0xffff, y0 = w0 >> 16;
         const int log2n = w1 & 255, comp = (w1 >> 8) & 255, mode = (w1 >> 16) & 255, flags = w1 >> 24;
@@ -1714,18 +1729,18 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
         // position of the block inside the tile (tile index 0 = sample -1 of the CTU)
         const int tx0 = x0 - (ctux >> sh) + IT_X0, ty0 = y0 - (ctuy >> sh) + 1;
         const int dcv = intra_references(comp ? tile_c[comp - 1] : tile_y, tw, (ty0 - 1) * tw + tx0 - 1, log2n, comp, mode, flags, w2, w3,
-                                         comp ? s.bd_c : s.bd_y, s.strong_intra, ref_s[wv], lane);
+                                         comp ? s.bd_c : s.bd_y, s.strong_intra, ref_s[slot], lane);
         if (two_phase) {
           if (lane == 0) {
-            blk_s[wv][0] = w0;
-            blk_s[wv][1] = in_range ? w1 : 0u;  // log2n = 0 marks a slot without a block
-            blk_s[wv][2] = w3;
-            blk_s[wv][3] = (unsigned)dcv;
+            blk_s[slot][0] = w0;
+            blk_s[slot][1] = in_range ? w1 : 0u;  // log2n = 0 marks a slot without a block
+            blk_s[slot][2] = w3;
+            blk_s[slot][3] = (unsigned)dcv;
           }
         } else {
           hr_wave_sync();  // the reference samples were written by other lanes of this wave
           if (in_range)
-            intra_predict(intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[wv]), lane, 64);
+            intra_predict(intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[slot], inv_tab), lane, 64);
         }
       }
       HR_STAMP(9)
@@ -1746,18 +1761,23 @@ __global__ __launch_bounds__(IT_NTHR) void k_intra(const PicJob *jobs, SeqInfo s
       const unsigned long long below = (1ull << lane) - 1;
       const int my_chunk0 = 4 * __popcll(__ballot(my_log2n == 5) & below) + __popcll(__ballot(my_log2n >= 2 && my_log2n <= 4) & below);
       const int my_nch = my_log2n == 5 ? 4 : 1;
-      unsigned long long mine = __ballot(my_log2n != 0 && ((wv - my_chunk0) & (IT_WAVES - 1)) < my_nch);
+      unsigned long long mine = __ballot(my_log2n != 0 && ((slot - my_chunk0) & (IT_WAVES - 1)) < my_nch);
       while (mine) {
         const int b = __ffsll((long long)mine) - 1;
         mine &= mine - 1;
         const unsigned w0 = (unsigned)hr_readlane((int)my0, b), w1 = (unsigned)hr_readlane((int)my1, b), w3 = (unsigned)hr_readlane((int)my2, b);
-        const int c0 = (wv - hr_readlane(my_chunk0, b)) & (IT_WAVES - 1);
+        const int c0 = (slot - hr_readlane(my_chunk0, b)) & (IT_WAVES - 1);
         const int dcv = hr_readlane((int)my3, b);
-        intra_predict(intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[b]),
+        intra_predict(intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[b], inv_tab),
                       c0 * 64 + lane, IT_WAVES * 64);
       }
       }
       HR_STAMP(11)
+      {
+        rword = hr_uniform(rword_next_v);
+        const int slot_n = (wv + 3 * (r + 1)) & (IT_WAVES - 1), b_n = (int)(rword & IR_BASE_MASK) + slot_n;
+        if (r + 1 < n_rounds && slot_n < (int)((rword >> IR_COUNT_SHIFT) & IR_COUNT_MASK)) q = *(const uint4 *)&items_s[b_n < nit ? b_n : 0];
+      }
       __syncthreads();  // the next round reads what this one wrote into the tile and reuses the block slots
       HR_STAMP(12)
 #ifdef HEVCRECON_INTRA_STAMPS
@@ -2479,15 +2499,18 @@ void hr_launch_output(const void *const planes[3], void *dst, const SeqInfo &s, 
   }
 }
 
-void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list, int n_items, int max_parallel, unsigned *ticket, hipStream_t st) {
+void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list, int n_items, int max_parallel, bool dense, unsigned *ticket,
+                     hipStream_t st) {
   // No more workgroups than CTUs that can ever be worked on at a time (the largest wave of the batch), and no more
-  // than fill the device a few times over: a workgroup that has drawn a CTU holds its place on the device while
-  // it waits for that CTU's neighbours.
+  // than fill the device: a workgroup that has drawn a CTU holds its place on the device while it waits for that
+  // CTU's neighbours.  One workgroup per compute unit as a rule: more of them crowd out the kernels of other engine
+  // contexts on the device (random-access streams measured 4 % slower with three).  A batch of intra pictures, where
+  // this kernel is most of the work, gets three for every two units: a chain of dependent LDS round trips per
+  // block leaves a unit's SIMDs idle most of the time, and a second context does the same (1080p all-intra, two
+  // contexts: 37.7 k -> 41.3 k frames/s).  HEVCRECON_INTRA_GRID overrides both.
   int grid = n_items < max_parallel ? n_items : max_parallel;
-  // (measured, 1080p, two engine contexts sharing the device: one workgroup per compute unit reconstructs the random
-  // access stream 4 % faster than three, which crowd out the other context's kernels, and the all-intra stream as fast;
-  // a single context with hundreds of all-intra pictures per batch gains from 768: HEVCRECON_INTRA_GRID overrides)
-  static const int cap = std::getenv("HEVCRECON_INTRA_GRID") ? std::atoi(std::getenv("HEVCRECON_INTRA_GRID")) : 256;
+  static const int forced = std::getenv("HEVCRECON_INTRA_GRID") ? std::atoi(std::getenv("HEVCRECON_INTRA_GRID")) : 0;
+  const int cap = forced > 0 ? forced : dense ? 384 : 256;
   if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
   if (s.bd_y <= 8 && s.bd_c <= 8)
