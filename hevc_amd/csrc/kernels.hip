@@ -11,7 +11,8 @@
 //                motion compensation straight from the per-4x4 motion records
 //   k_transform  one lane per column/row of a transform block: de-quantisation + 2-D inverse
 //                transform, result added to the picture (inter) or kept as residual (intra)
-//   k_intra      one workgroup per CTU (CTU staged in LDS, blocks level by level inside), one launch per CTU wave
+//   k_intra      one workgroup per CTU at a time (CTU staged in LDS, blocks level by level inside), one launch per batch:
+//                resident workgroups draw CTUs in dependency order and wait for their neighbours on device flags
 //   k_deblock    one lane per 4-sample edge segment; vertical edges, then horizontal edges
 //   k_sao        one lane per 16 samples, out of place (deblocked picture -> final picture)
 #ifdef HEVCRECON_EMULATE
@@ -1385,37 +1386,44 @@ __device__ __forceinline__ IntraBlk intra_blk(const SeqInfo &s, uint16_t *tile_y
 }
 
 // Prediction + residual + clip of one intra block, written into the CTU tile (TLibCommon/TComPrediction.cpp:183-390,
-// 691-763).  The block is cut into groups of four samples that lie side by side ACROSS the prediction direction (in
+// 691-763).  The block is cut into groups of G samples that lie side by side ACROSS the prediction direction (in
 // a row for planar, DC and the vertical modes; in a column for the horizontal modes, which are the vertical ones on
-// the transposed block: sgn flips the index direction of the reference array).  The four samples of a group share
-// their position along the direction -- so the angular modes' reference offset and fraction -- and read five
-// neighbouring reference samples; row groups load their residual and store their result as 8 bytes.  This call
-// handles groups g_first, g_first + g_step, ...
+// the transposed block: sgn flips the index direction of the reference array).  The samples of a group share
+// their position along the direction -- so the angular modes' reference offset and fraction -- and read G + 1
+// neighbouring reference samples; row groups of four load their residual and store their result as 8 bytes.
+// G = 4 for blocks of 16x16 and more (a 16x16 block is one pass of a wave), G = 1 for the small ones, where one
+// sample per lane is the shorter chain.  This call handles groups g_first, g_first + g_step, ...
+template <int G>
 __device__ __forceinline__ void intra_predict(const IntraBlk &B, int g_first, int g_step) {
-  const int log2n = B.log2n, n = 1 << log2n, ngr = (n * n) >> 2;
+  constexpr int LG = G == 4 ? 2 : 0;
+  static_assert(G == 4 || G == 1, "groups of four samples or single samples");
+  const int log2n = B.log2n, n = 1 << log2n, ngr = (n * n) >> LG;
   const int mode = B.mode, maxv = B.maxv, tw = B.tw, rw = B.rw, dcv = B.dcv;
   const uint16_t *cn = B.cn;
   const bool hor = mode >= 2 && mode < 18;
   const int sgn = hor ? -1 : 1;  // MAIN(i) = cn[sgn * i], SIDE(i) = cn[-sgn * i]
   const int angle = B.angle, inv = B.inv;
   for (int g = g_first; g < ngr; g += g_step) {
-    const int kk = g >> (log2n - 2);              // position along the prediction direction
-    const int ee = (g & ((n >> 2) - 1)) << 2;     // first of the four positions across it
-    int v[4];
+    // kk: position along the prediction direction, ee: first of the G positions across it.  Neighbouring lanes take
+    // neighbouring columns either way (kk for the horizontal modes, ee for the others), so that a wave's tile and
+    // residual accesses run along rows.
+    const int kk = hor ? g & (n - 1) : g >> (log2n - LG);
+    const int ee = hor ? (g >> log2n) << LG : (g & ((n >> LG) - 1)) << LG;
+    int v[G];
     if (mode == 0) {  // planar: kk = row, ee = column
       const int left = cn[-1 - kk], tr = cn[1 + n], bl = cn[-1 - n];
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
+      for (int e = 0; e < G; e++) {
         const int top = cn[1 + ee + e];
         v[e] = ((left << log2n) + n + __mul24(ee + e + 1, tr - left) + (top << log2n) + __mul24(kk + 1, bl - top)) >> (log2n + 1);
       }
     } else if (mode == 1) {  // DC, with its edge smoothing for luma blocks up to 16x16
 #pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = dcv;
+      for (int e = 0; e < G; e++) v[e] = dcv;
       if (B.edge) {
         if (kk == 0) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = (cn[1 + ee + e] + 3 * dcv + 2) >> 2;
+          for (int e = 0; e < G; e++) v[e] = (cn[1 + ee + e] + 3 * dcv + 2) >> 2;
           if (ee == 0) v[0] = (cn[1] + cn[-1] + 2 * dcv + 2) >> 2;
         } else if (ee == 0) {
           v[0] = (cn[-1 - kk] + 3 * dcv + 2) >> 2;
@@ -1423,38 +1431,47 @@ __device__ __forceinline__ void intra_predict(const IntraBlk &B, int g_first, in
       }
     } else if (angle == 0) {  // pure vertical / horizontal
 #pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = cn[sgn * (ee + e + 1)];
+      for (int e = 0; e < G; e++) v[e] = cn[sgn * (ee + e + 1)];
       if (B.edge && ee == 0) v[0] = clip3i(0, maxv, cn[sgn] + ((cn[-sgn * (kk + 1)] - cn[0]) >> 1));
     } else {
       const int t = __mul24(kk + 1, angle), i0 = ee + 1 + (t >> 5), f = t & 31;
-      int m[5];
+      int m[G + 1];
       if (angle > 0) {
 #pragma unroll
-        for (int j = 0; j < 5; j++) m[j] = cn[sgn * (i0 + j)];
+        for (int j = 0; j < G + 1; j++) m[j] = cn[sgn * (i0 + j)];
       } else {
         // negative indices address the side reference projected onto the main one
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
+        for (int j = 0; j < G + 1; j++) {
           const int idx = i0 + j;
           m[j] = cn[idx >= 0 ? sgn * idx : -sgn * ((128 - __mul24(idx, inv)) >> 8)];
         }
       }
       // (f = 0 gives m[e] exactly, so the interpolation needs no special case)
 #pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = (__mul24(32 - f, m[e]) + __mul24(f, m[e + 1]) + 16) >> 5;
+      for (int e = 0; e < G; e++) v[e] = (__mul24(32 - f, m[e]) + __mul24(f, m[e + 1]) + 16) >> 5;
+    }
+    if constexpr (G == 4) {
+      if (!hor) {
+        const int at = __mul24(kk, tw) + ee;
+        if (B.has_resi) {
+          const uint2 r = *(const uint2 *)(B.resi0 + __mul24(kk, rw) + ee);
+          v[0] += (int)(int16_t)(r.x & 0xffffu), v[1] += (int)r.x >> 16, v[2] += (int)(int16_t)(r.y & 0xffffu), v[3] += (int)r.y >> 16;
+        }
+#pragma unroll
+        for (int e = 0; e < G; e++) v[e] = clip3i(0, maxv, v[e]);
+        *(uint2 *)(B.tile0 + at) = make_uint2((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16));
+        continue;
+      }
     }
     if (!hor) {
-      const int at = __mul24(kk, tw) + ee;
-      if (B.has_resi) {
-        const uint2 r = *(const uint2 *)(B.resi0 + __mul24(kk, rw) + ee);
-        v[0] += (int)(int16_t)(r.x & 0xffffu), v[1] += (int)r.x >> 16, v[2] += (int)(int16_t)(r.y & 0xffffu), v[3] += (int)r.y >> 16;
-      }
-#pragma unroll
-      for (int e = 0; e < 4; e++) v[e] = clip3i(0, maxv, v[e]);
-      *(uint2 *)(B.tile0 + at) = make_uint2((unsigned)v[0] | ((unsigned)v[1] << 16), (unsigned)v[2] | ((unsigned)v[3] << 16));
+      // (single samples) kk = row, ee = column
+      int x = v[0];
+      if (B.has_resi) x += B.resi0[__mul24(kk, rw) + ee];
+      B.tile0[__mul24(kk, tw) + ee] = (uint16_t)clip3i(0, maxv, x);
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
+      for (int e = 0; e < G; e++) {
         int x = v[e];
         if (B.has_resi) x += B.resi0[__mul24(ee + e, rw) + kk];
         B.tile0[__mul24(ee + e, tw) + kk] = (uint16_t)clip3i(0, maxv, x);
@@ -1487,14 +1504,14 @@ __global__ __launch_bounds__(256) void k_transform_small(const PicJob *jobs, Seq
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_intra: intra prediction + residual add.  One workgroup per CTU, one launch per CTU wave.
+// k_intra: intra prediction + residual add.  One launch per batch; a workgroup works on one CTU at a time.
 // ------------------------------------------------------------------------------------------------
 // The CTU's samples live in LDS together with the row above it (which reaches 32 samples into the
-// above-right CTU, as far as any block's above-right neighbours go) and the column left of it.  CTUs of one
-// wave are independent: everything they read from outside was finished by earlier launches (inter
-// prediction, earlier waves).  Inside the CTU the blocks are processed level by level (blocks of a level do
-// not depend on each other), IT_WAVES blocks per round: first one wave per block gathers, substitutes and
-// smooths the block's reference samples, then all waves share the samples to predict, 64 at a time.
+// above-right CTU, as far as any block's above-right neighbours go) and the column left of it.  What a CTU reads
+// from outside was finished by earlier launches (inter prediction) or by neighbouring CTUs of this launch, whose
+// "done" words the workgroup waits for.  Inside the CTU the blocks are processed level by level (blocks of a level
+// do not depend on each other), IT_WAVES blocks per round: one wave per block gathers, substitutes and smooths the
+// block's reference samples and predicts the block; the passes of a 32x32 block are shared out among the waves.
 //
 // Reference-sample array r[0..4n]: r[2n] is the corner, r[2n-1-j] the left column going down,
 // r[2n+1+i] the row above going right (TComPattern::initAdiPattern / fillReferenceSamples,
@@ -1739,8 +1756,13 @@ __global__ __launch_bounds__(IT_NTHR, HEVCRECON_INTRA_MIN_WAVES) void k_intra(co
           }
         } else {
           hr_wave_sync();  // the reference samples were written by other lanes of this wave
-          if (in_range)
-            intra_predict(intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[slot], inv_tab), lane, 64);
+          if (in_range) {
+            const IntraBlk B = intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[slot], inv_tab);
+            if (log2n >= 4)
+              intra_predict<4>(B, lane, 64);
+            else
+              intra_predict<1>(B, lane, 64);
+          }
         }
       }
       HR_STAMP(9)
@@ -1749,8 +1771,9 @@ __global__ __launch_bounds__(IT_NTHR, HEVCRECON_INTRA_MIN_WAVES) void k_intra(co
       HR_STAMP(10)
       // ---- phase B: prediction + residual + store (TLibCommon/TComPrediction.cpp:183-390,691-763), all waves
       //      over all blocks of the round, 64 groups of four samples at a time
-      // Lane b < nb fetches block b's slot; a block is cut into chunks of 64 groups of four samples (a 32x32 block into
-      // four, smaller ones are one chunk), chunk g of the round belongs to wave g % IT_WAVES.  Every wave finds the blocks it has a chunk of with three ballots instead of
+      // Lane b < nb fetches block b's slot; a block is cut into chunks of 64 groups of samples (a 32x32 block into
+      // four; a 16x16 block, in groups of four, and the small ones, sample by sample, are one chunk), chunk g of the
+      // round belongs to wave g % IT_WAVES.  Every wave finds the blocks it has a chunk of with three ballots instead of
       // walking the slots one dependent LDS read after the other.
       unsigned my0 = 0, my1 = 0, my2 = 0, my3 = 0;
       if (lane < nb) {
@@ -1768,8 +1791,11 @@ __global__ __launch_bounds__(IT_NTHR, HEVCRECON_INTRA_MIN_WAVES) void k_intra(co
         const unsigned w0 = (unsigned)hr_readlane((int)my0, b), w1 = (unsigned)hr_readlane((int)my1, b), w3 = (unsigned)hr_readlane((int)my2, b);
         const int c0 = (slot - hr_readlane(my_chunk0, b)) & (IT_WAVES - 1);
         const int dcv = hr_readlane((int)my3, b);
-        intra_predict(intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[b], inv_tab),
-                      c0 * 64 + lane, IT_WAVES * 64);
+        const IntraBlk B = intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[b], inv_tab);
+        if (B.log2n >= 4)
+          intra_predict<4>(B, c0 * 64 + lane, IT_WAVES * 64);
+        else
+          intra_predict<1>(B, c0 * 64 + lane, IT_WAVES * 64);
       }
       }
       HR_STAMP(11)

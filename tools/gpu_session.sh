@@ -1,8 +1,13 @@
 set -e
 mkdir -p gpurun_out
 IB="--fixture intra_main_1920x1080 --seeds 1 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --check-two-streams-only"
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gputests.log 2>&1
-HEVCRECON_LIB=$PWD/hevc_amd/libhevcrecon_stamps.so timeout -k 10 200 python bench.py $IB --contexts 1 --streams 64 > gpurun_out/bench_intra_stamps.json 2> gpurun_out/bench_intra_stamps.err
-timeout -k 10 200 python bench.py $IB > gpurun_out/bench_intra.json 2> gpurun_out/bench_intra.err
-timeout -k 10 300 python bench.py --no-cpu-baseline --no-handover > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+run() { name=$1; shift; "$@" > gpurun_out/x_$name.json 2> gpurun_out/x_$name.err; python3 -c "
+import json,sys
+d=json.load(open('gpurun_out/x_$name.json')); print('$name', d['value'], d['kernels']['k_intra'], d.get('fewer_streams'))"; }
+timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py -m gpu -x -q --timeout 300 --timeout-method thread -k "not drop_in" > gpurun_out/gputests.log 2>&1
+run new timeout -k 10 300 python bench.py --no-cpu-baseline --no-handover --steps 3
+HEVCRECON_LIB=$PWD/hevc_amd/libhevcrecon_lb1.so run new_lb1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-handover --steps 3
+HEVCRECON_LIB=$PWD/hevc_amd/libhevcrecon_old.so run old timeout -k 10 300 python bench.py --no-cpu-baseline --no-handover --steps 3
+run new_intra timeout -k 10 200 python bench.py $IB
+HEVCRECON_LIB=$PWD/hevc_amd/libhevcrecon_lb1.so run new_lb1_intra timeout -k 10 200 python bench.py $IB
 echo ALLDONE
