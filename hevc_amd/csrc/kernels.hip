@@ -78,6 +78,7 @@ __device__ __forceinline__ unsigned hr_ticket_take(unsigned *p) { return __atomi
 __device__ __forceinline__ unsigned hr_flag_read(const unsigned *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 __device__ __forceinline__ void hr_flag_raise(unsigned *p) { __atomic_store_n(p, 1u, __ATOMIC_RELEASE); }
 __device__ __forceinline__ void hr_store_through(unsigned long long *p, unsigned long long v) { *p = v; }
+__device__ __forceinline__ void hr_store_through16(void *p, uint4 v) { *(uint4 *)p = v; }
 __device__ __forceinline__ void hr_drain_stores() {}
 __device__ __forceinline__ void hr_acquire() {}
 __device__ __forceinline__ void hr_nap() {}
@@ -96,6 +97,14 @@ __device__ __forceinline__ unsigned hr_flag_read(const unsigned *p) {
 __device__ __forceinline__ void hr_flag_raise(unsigned *p) { __hip_atomic_store((hr_gu32 *)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void hr_store_through(unsigned long long *p, unsigned long long v) {
   __hip_atomic_store((hr_gu64 *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 16 bytes written through to memory in one fabric write (an 8-byte write-through store costs as much).  The
+// compiler does not see the store: its data registers are only free again once the instruction has read them
+// (hence the s_nop inside the string), and the wave counts it in vmcnt like any other store (hr_drain_stores).
+__device__ __forceinline__ void hr_store_through16(void *p, uint4 v) {
+  typedef unsigned hr_v4u __attribute__((ext_vector_type(4)));
+  const hr_v4u d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
 }
 __device__ __forceinline__ void hr_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void hr_acquire() {
@@ -1812,31 +1821,39 @@ __global__ __launch_bounds__(IT_NTHR, HEVCRECON_INTRA_MIN_WAVES) void k_intra(co
   }
   HR_STAMP(3)
   // ---- write the CTU back (in P/B pictures the inter samples staged above go back unchanged) ----
-  // Eight bytes per store, written through to memory: a neighbouring CTU may be waiting for these samples in another
-  // workgroup of this launch.  (Picture widths are multiples of 8 luma samples; a chroma store that begins inside
-  // the picture may end in the row's padding.)
+  // Sixteen bytes per store, written through to memory: a neighbouring CTU may be waiting for these samples in another
+  // workgroup of this launch.  (Rows are padded to a multiple of 128 samples, so a store that begins inside the
+  // picture may end in the row's padding; it never reaches into another CTU.)
   {
-    constexpr int SPS = 8 / sizeof(pel_t);  // samples per store
-    auto pack8 = [](const uint16_t *t) -> unsigned long long {
-      if constexpr (sizeof(pel_t) == 1)
-        return (unsigned long long)pack4(t[0], t[1], t[2], t[3]) | ((unsigned long long)pack4(t[4], t[5], t[6], t[7]) << 32);
-      else
-        return (unsigned long long)t[0] | ((unsigned long long)t[1] << 16) | ((unsigned long long)t[2] << 32) | ((unsigned long long)t[3] << 48);
+    constexpr int SPS = 16 / sizeof(pel_t);  // samples per store
+    // 16 bytes of a tile row (SPS samples, two per dword) -> SPS samples of the picture
+    auto pack16b = [](const uint16_t *t) -> uint4 {
+      const uint2 *q = (const uint2 *)t;
+      if constexpr (sizeof(pel_t) == 1) {
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint2 d = q[j];  // samples 4j .. 4j+3
+          o[j] = (d.x & 0xffu) | ((d.x >> 8) & 0xff00u) | ((d.y & 0xffu) << 16) | ((d.y & 0xff0000u) << 8);
+        }
+        return make_uint4(o[0], o[1], o[2], o[3]);
+      } else {
+        const uint2 a = q[0], b = q[1];
+        return make_uint4(a.x, a.y, b.x, b.y);
+      }
     };
     pel_t *py = (pel_t *)J.rec[0];
     for (int i = tid; i < 64 * 64 / SPS; i += IT_NTHR) {
       const int ty = i / (64 / SPS), tx = (i % (64 / SPS)) * SPS;
       const int gx = ctux + tx, gy = ctuy + ty;
-      if (gx < s.w && gy < s.h) hr_store_through((unsigned long long *)(py + (size_t)gy * s.stride_y + gx), pack8(&tile_y[(ty + 1) * IT_YW + tx + IT_X0]));
+      if (gx < s.w && gy < s.h) hr_store_through16(py + (size_t)gy * s.stride_y + gx, pack16b(&tile_y[(ty + 1) * IT_YW + tx + IT_X0]));
     }
-#pragma unroll
-    for (int c = 0; c < 2; c++) {
-      pel_t *pc = (pel_t *)J.rec[1 + c];
-      for (int i = tid; i < 32 * 32 / SPS; i += IT_NTHR) {
-        const int ty = i / (32 / SPS), tx = (i % (32 / SPS)) * SPS;
-        const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
-        if (gx < s.cw && gy < s.ch) hr_store_through((unsigned long long *)(pc + (size_t)gy * s.stride_c + gx), pack8(&tile_c[c][(ty + 1) * IT_CW + tx + IT_X0]));
-      }
+    for (int i = tid; i < 2 * 32 * 32 / SPS; i += IT_NTHR) {
+      const int c = i / (32 * 32 / SPS), r = i % (32 * 32 / SPS);
+      const int ty = r / (32 / SPS), tx = (r % (32 / SPS)) * SPS;
+      const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
+      if (gx < s.cw && gy < s.ch)
+        hr_store_through16((pel_t *)J.rec[1 + c] + (size_t)gy * s.stride_c + gx, pack16b(&tile_c[c][(ty + 1) * IT_CW + tx + IT_X0]));
     }
   }
   HR_STAMP(4)

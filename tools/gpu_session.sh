@@ -4,10 +4,8 @@ IB="--fixture intra_main_1920x1080 --seeds 1 --steps 2 --warmup 1 --no-cpu-basel
 run() { name=$1; shift; "$@" > gpurun_out/x_$name.json 2> gpurun_out/x_$name.err; python3 -c "
 import json,sys
 d=json.load(open('gpurun_out/x_$name.json')); print('$name', d['value'], d['kernels']['k_intra'], d.get('fewer_streams'))"; }
-timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py -m gpu -x -q --timeout 300 --timeout-method thread -k "not drop_in" > gpurun_out/gputests.log 2>&1
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gputests.log 2>&1
 run new timeout -k 10 300 python bench.py --no-cpu-baseline --no-handover --steps 3
-HEVCRECON_LIB=$PWD/hevc_amd/libhevcrecon_lb1.so run new_lb1 timeout -k 10 300 python bench.py --no-cpu-baseline --no-handover --steps 3
-HEVCRECON_LIB=$PWD/hevc_amd/libhevcrecon_old.so run old timeout -k 10 300 python bench.py --no-cpu-baseline --no-handover --steps 3
 run new_intra timeout -k 10 200 python bench.py $IB
-HEVCRECON_LIB=$PWD/hevc_amd/libhevcrecon_lb1.so run new_lb1_intra timeout -k 10 200 python bench.py $IB
+run new_he10 timeout -k 10 300 python bench.py --fixture randomaccess_he10_1920x1080 --seeds 1 --no-extras --no-cpu-baseline --steps 3
 echo ALLDONE
