@@ -486,6 +486,44 @@ def main():
                     engs[1].reconstruct_prepared(preps[1][(t + npic // 2) % npic])
             sync()
             side["streams_8_over_two_contexts_frames_per_s"] = round(2 * npic * 8 / (time.perf_counter() - t0), 1)
+        if len(groups[0]) >= 2:
+            # 8 streams over four fresh contexts of 2 (four is the number of hardware queues a process gets): what 64
+            # streams over 8 GPUs can get out of each device
+            n_ctx, n_str = 4, 8
+            engs4 = [engine.Engine(sp, device=local_rank) for _ in range(n_ctx)]
+            syn4 = [[None] * n_str for _ in range(npic)]
+            for k, seq in enumerate(seqs):
+                for t, pic in enumerate(seq.pictures):
+                    for s4 in range(n_str):
+                        if s4 % len(seqs) == k:
+                            syn4[t][s4] = engs4[s4 % n_ctx].new_syntax().pack(clone_for_stream(pic, s4))
+                    pic.drop_ctypes()
+            preps = [[engs4[c].prepare_batch([syn4[t][s4] for s4 in range(c, n_str, n_ctx)],
+                                             [seqs[s4 % len(seqs)].pictures[t].pic_id + s4 * ID_STRIDE for s4 in range(c, n_str, n_ctx)])
+                      for t in range(npic)] for c in range(n_ctx)]
+            # the contexts start a quarter of a pass apart; once each has played a whole pass (every picture is on the
+            # device then) two passes are timed
+            def play(t_from, t_to):
+                for t in range(t_from, t_to):
+                    for c in range(n_ctx):
+                        tt = t - c * npic // n_ctx
+                        if tt >= 0:
+                            engs4[c].reconstruct_prepared(preps[c][tt % npic])
+            t_start = (n_ctx - 1) * npic // n_ctx + npic
+            play(0, t_start)
+            for e in engs4:
+                e.synchronize()
+            t0 = time.perf_counter()
+            play(t_start, t_start + 2 * npic)
+            for e in engs4:
+                e.synchronize()
+            side["streams_8_over_four_contexts_frames_per_s"] = round(2 * npic * n_str / (time.perf_counter() - t0), 1)
+            for row in syn4:
+                for y in row:
+                    if y is not None:
+                        y.close()
+            for e in engs4:
+                e.close()
         if not args.stagger and S >= 2 * C:
             W.set_offsets(True)
             gg = 0
@@ -498,6 +536,25 @@ def main():
             gg = run_passes(gg, 2)
             sync()
             side["every_stream_at_its_own_position_frames_per_s"] = round(2 * npic * S / (time.perf_counter() - t0), 1)
+            if C != 4 and S >= 8:
+                # the same over four contexts: with an I picture in every batch the intra kernel's dependency chains are
+                # what a batch waits for, and four batches in flight hide more of them than two
+                W4 = Workload(seqs, S, 4, local_rank, False, True)
+                gg = 0
+                while gg < W4.max_off:
+                    W4.step(gg)
+                    gg += 1
+                for _ in range(npic):
+                    W4.step(gg)
+                    gg += 1
+                W4.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2 * npic):
+                    W4.step(gg)
+                    gg += 1
+                W4.synchronize()
+                side["every_stream_at_its_own_position_over_four_contexts_frames_per_s"] = round(2 * npic * S / (time.perf_counter() - t0), 1)
+                W4.close()
         result["fewer_streams"] = side
         e2e = end_to_end(local_rank)
         if e2e is not None:

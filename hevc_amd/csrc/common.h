@@ -85,12 +85,10 @@ struct McBlk {
 // each.  (90 levels and 384 blocks give at most 90 + 384 / 8 rounds.)
 #define HR_INTRA_ROUND_BLOCKS 8
 #define HR_INTRA_MAX_ROUNDS 144
-// A round as the kernel reads it: first block (relative to the CTU's first), number of blocks, and whether the round
-// holds a 32x32 block (its prediction is then spread over all waves)
+// A round as the kernel reads it: first block (relative to the CTU's first) and number of blocks
 #define IR_BASE_MASK 0x1ff
 #define IR_COUNT_SHIFT 9
 #define IR_COUNT_MASK 0xf
-#define IR_BIG 0x2000
 
 #define IN_CORNER 0x01
 #define IN_HAS_RESI 0x02

@@ -1542,7 +1542,7 @@ void hr_intra_stamps_report() {
   unsigned long long v[16];
   if (hipMemcpyFromSymbol(v, HIP_SYMBOL(hr_intra_stamps), sizeof v) != hipSuccess) return;
   const char *names[16] = {"ticket", "wait for neighbours", "staging", "rounds (rest)", "write-back issue", "drain + barrier", "CTUs", "rounds",
-                           "round: set-up", "round: references", "round: barrier 1", "round: prediction", "round: barrier 2", "two-phase rounds", "", ""};
+                           "round: set-up", "round: references + prediction", "", "", "round: barrier", "", "", ""};
   for (int k = 0; k < 14; k++) fprintf(stderr, "k_intra %-20s %llu\n", names[k], v[k]);
 }
 #else
@@ -1561,7 +1561,6 @@ __global__ __launch_bounds__(IT_NTHR, HEVCRECON_INTRA_MIN_WAVES) void k_intra(co
   __shared__ __attribute__((aligned(16))) IntraItem items_s[IT_MAX_ITEMS];
   __shared__ uint16_t rounds_s[IT_MAX_ROUNDS];
   __shared__ uint16_t ref_s[IT_WAVES][IT_REFW];
-  __shared__ __attribute__((aligned(16))) unsigned blk_s[IT_WAVES][4];  // per block of a two-phase round: item words 0, 1 and 3, DC value
   __shared__ unsigned ticket_s;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int inv_tab = kIntraInvAngle[lane & 15];
@@ -1732,91 +1731,45 @@ __global__ __launch_bounds__(IT_NTHR, HEVCRECON_INTRA_MIN_WAVES) void k_intra(co
     if (wv < (int)((rword >> IR_COUNT_SHIFT) & IR_COUNT_MASK)) q = *(const uint4 *)&items_s[b0 < nit ? b0 : 0];
   }
   for (int r = 0; r < n_rounds; r++) {
-      // The round: its first block, how many, and whether a 32x32 block is among them (the packer's table).
-      // A round without a 32x32 block is finished by the waves that build the references: each predicts its own
-      // block in one pass and the round costs one barrier.  The four passes of a 32x32 block are worth spreading
-      // over the waves, at the price of a hand-over through LDS and a second barrier.
+      // The round: its first block and how many (the packer's table).  One wave per block builds the block's
+      // reference samples and predicts it: one pass of the wave for blocks up to 16x16, four for a 32x32 block, and
+      // the round costs one barrier.  (Handing the passes of a 32x32 block to the other waves through LDS, at the
+      // price of a second barrier, measured the same.)
       const int rbase = rword & IR_BASE_MASK, nb = min((int)((rword >> IR_COUNT_SHIFT) & IR_COUNT_MASK), IT_WAVES);
-      const bool two_phase = (rword & IR_BIG) != 0;
       const unsigned rword_next_v = rounds_s[r + 1 < n_rounds ? r + 1 : r];
       HR_STAMP(8)
-      // ---- phase A: one wave per block builds its reference samples ----
       // (which wave takes which block rotates from round to round: workgroups that share a compute unit then spread
       // their busy waves over its four SIMDs instead of all loading the first ones)
       const int slot = (wv + 3 * r) & (IT_WAVES - 1);
-      if (slot < nb) {
-        const bool in_range = rbase + slot < nit;
+      if (slot < nb && rbase + slot < nit) {
         // The block's description is the same in every lane: keep it in scalar registers.
         const unsigned w0 = hr_uniform(q.x), w1 = hr_uniform(q.y), w2 = hr_uniform(q.z), w3 = hr_uniform(q.w);
         const int x0 = w0 & 0xffff, y0 = w0 >> 16;
         const int log2n = w1 & 255, comp = (w1 >> 8) & 255, mode = (w1 >> 16) & 255, flags = w1 >> 24;
         const int sh = comp ? 1 : 0;
         const int tw = comp ? IT_CW : IT_YW;
-        // position of the block inside the tile (tile index 0 = sample -1 of the CTU)
+        // position of the block inside the tile (tile row 0 = the row above the CTU, tile column IT_X0 = its first column)
         const int tx0 = x0 - (ctux >> sh) + IT_X0, ty0 = y0 - (ctuy >> sh) + 1;
         const int dcv = intra_references(comp ? tile_c[comp - 1] : tile_y, tw, (ty0 - 1) * tw + tx0 - 1, log2n, comp, mode, flags, w2, w3,
                                          comp ? s.bd_c : s.bd_y, s.strong_intra, ref_s[slot], lane);
-        if (two_phase) {
-          if (lane == 0) {
-            blk_s[slot][0] = w0;
-            blk_s[slot][1] = in_range ? w1 : 0u;  // log2n = 0 marks a slot without a block
-            blk_s[slot][2] = w3;
-            blk_s[slot][3] = (unsigned)dcv;
-          }
-        } else {
-          hr_wave_sync();  // the reference samples were written by other lanes of this wave
-          if (in_range) {
-            const IntraBlk B = intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[slot], inv_tab);
-            if (log2n >= 4)
-              intra_predict<4>(B, lane, 64);
-            else
-              intra_predict<1>(B, lane, 64);
-          }
-        }
+        hr_wave_sync();  // the reference samples were written by other lanes of this wave
+        const IntraBlk B = intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[slot], inv_tab);
+        if (log2n >= 4)
+          intra_predict<4>(B, lane, 64);
+        else
+          intra_predict<1>(B, lane, 64);
       }
       HR_STAMP(9)
-      if (two_phase) {
-      __syncthreads();
-      HR_STAMP(10)
-      // ---- phase B: prediction + residual + store (TLibCommon/TComPrediction.cpp:183-390,691-763), all waves
-      //      over all blocks of the round, 64 groups of four samples at a time
-      // Lane b < nb fetches block b's slot; a block is cut into chunks of 64 groups of samples (a 32x32 block into
-      // four; a 16x16 block, in groups of four, and the small ones, sample by sample, are one chunk), chunk g of the
-      // round belongs to wave g % IT_WAVES.  Every wave finds the blocks it has a chunk of with three ballots instead of
-      // walking the slots one dependent LDS read after the other.
-      unsigned my0 = 0, my1 = 0, my2 = 0, my3 = 0;
-      if (lane < nb) {
-        const uint4 q = *(const uint4 *)blk_s[lane];
-        my0 = q.x, my1 = q.y, my2 = q.z, my3 = q.w;
-      }
-      const int my_log2n = my1 & 255;
-      const unsigned long long below = (1ull << lane) - 1;
-      const int my_chunk0 = 4 * __popcll(__ballot(my_log2n == 5) & below) + __popcll(__ballot(my_log2n >= 2 && my_log2n <= 4) & below);
-      const int my_nch = my_log2n == 5 ? 4 : 1;
-      unsigned long long mine = __ballot(my_log2n != 0 && ((slot - my_chunk0) & (IT_WAVES - 1)) < my_nch);
-      while (mine) {
-        const int b = __ffsll((long long)mine) - 1;
-        mine &= mine - 1;
-        const unsigned w0 = (unsigned)hr_readlane((int)my0, b), w1 = (unsigned)hr_readlane((int)my1, b), w3 = (unsigned)hr_readlane((int)my2, b);
-        const int c0 = (slot - hr_readlane(my_chunk0, b)) & (IT_WAVES - 1);
-        const int dcv = hr_readlane((int)my3, b);
-        const IntraBlk B = intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[b], inv_tab);
-        if (B.log2n >= 4)
-          intra_predict<4>(B, c0 * 64 + lane, IT_WAVES * 64);
-        else
-          intra_predict<1>(B, c0 * 64 + lane, IT_WAVES * 64);
-      }
-      }
-      HR_STAMP(11)
       {
+        // the next round's description and this wave's block of it: read now, used after the barrier
         rword = hr_uniform(rword_next_v);
         const int slot_n = (wv + 3 * (r + 1)) & (IT_WAVES - 1), b_n = (int)(rword & IR_BASE_MASK) + slot_n;
         if (r + 1 < n_rounds && slot_n < (int)((rword >> IR_COUNT_SHIFT) & IR_COUNT_MASK)) q = *(const uint4 *)&items_s[b_n < nit ? b_n : 0];
       }
-      __syncthreads();  // the next round reads what this one wrote into the tile and reuses the block slots
+      __syncthreads();  // the next round reads what this one wrote into the tile and reuses the reference arrays
       HR_STAMP(12)
 #ifdef HEVCRECON_INTRA_STAMPS
-      if (tid == 0) acc_[7] += 1, acc_[13] += two_phase ? 1 : 0;
+      if (tid == 0) acc_[7] += 1;
 #endif
   }
   HR_STAMP(3)

@@ -257,9 +257,7 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
     for (int l = 1; l <= nlev; l++)
       for (int b = first[l]; b < first[l + 1]; b += HR_INTRA_ROUND_BLOCKS) {
         const int nb = std::min<int>(HR_INTRA_ROUND_BLOCKS, first[l + 1] - b);
-        bool big = false;
-        for (int k = 0; k < nb; k++) big = big || intra[ic.item_start + b + k].log2n == 5;
-        rounds.push_back((uint16_t)(b | (nb << IR_COUNT_SHIFT) | (big ? IR_BIG : 0)));
+        rounds.push_back((uint16_t)(b | (nb << IR_COUNT_SHIFT)));
       }
     if (rounds.size() - ic.round_start > HR_INTRA_MAX_ROUNDS) {
       error = "CTU holds more intra blocks or dependency levels than a 64x64 CTU can";
