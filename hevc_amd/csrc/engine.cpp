@@ -1055,7 +1055,9 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
     Timed tm(c, K_INTRA, 1, !ws.fixed);
     // "dense": pictures coded mostly in intra blocks, and enough of them to keep more workgroups busy
     const bool dense = n >= 8 && n_intra_ctus * 4 >= (size_t)n * s.ctus_w * s.ctus_h * 3;
-    hr_launch_intra(jd, s, intra_list, (int)n_intra_ctus, intra_parallel, dense, ws.sync_dev, c->stream);
+    bool inside = false;
+    for (int i = 0; i < n; i++) inside = inside || jh[i].slice_type != 2 || jh[i].has_pcm;
+    hr_launch_intra(jd, s, intra_list, (int)n_intra_ctus, intra_parallel, dense, inside, ws.sync_dev, c->stream);
   }
   if (stages) {
     Timed tm(c, K_COPY, 1);

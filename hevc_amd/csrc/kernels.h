@@ -14,9 +14,10 @@ void hr_launch(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_
 // a single picture (its ictu[] is in such an order already).  `ticket` and every picture's ctu_done words must be
 // zero when the kernel starts.
 // max_parallel: the most CTUs that can be in work at a time (the batch's largest wave); dense: the batch's pictures are
-// coded mostly in intra blocks (the launch then gets more workgroups).
-void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list, int n_items, int max_parallel, bool dense, unsigned *ticket,
-                     hipStream_t stream);
+// coded mostly in intra blocks (the launch then gets more workgroups); inside: some picture of the batch is not a plain
+// intra picture (its CTUs hold inter-predicted or IPCM samples that have to be staged).
+void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list, int n_items, int max_parallel, bool dense, bool inside,
+                     unsigned *ticket, hipStream_t stream);
 
 // Converts picture planes to the bytes TVideoIOYuv::write puts into a file: width x height samples of each plane
 // (chroma: half of each), `file_bd` bits deep (scaled from the internal depth with rounding and clipping, or shifted

@@ -1549,11 +1549,12 @@ void hr_intra_stamps_report() {
 #define HR_STAMP(k)
 #endif
 
-template <typename pel_t>
-#ifndef HEVCRECON_INTRA_MIN_WAVES
-#define HEVCRECON_INTRA_MIN_WAVES 6 /* waves per SIMD that the register allocation leaves room for: three workgroups per compute unit */
-#endif
-__global__ __launch_bounds__(IT_NTHR, HEVCRECON_INTRA_MIN_WAVES) void k_intra(const PicJob *jobs, SeqInfo s, const unsigned *list, int n_items, unsigned *ticket) {
+// INSIDE: the batch holds pictures whose CTUs carry samples before this kernel runs (inter prediction in P and B
+// pictures, IPCM units): those CTUs are staged whole -- their samples are requested before the wait for the
+// neighbours, like the residual -- where a batch of plain intra pictures needs the borders only.  Two
+// instantiations, so that the second keeps the registers free for three workgroups per compute unit.
+template <typename pel_t, bool INSIDE>
+__global__ __launch_bounds__(IT_NTHR, INSIDE ? 4 : 6) void k_intra(const PicJob *jobs, SeqInfo s, const unsigned *list, int n_items, unsigned *ticket) {
   __shared__ __attribute__((aligned(16))) uint16_t tile_y[65 * IT_YW];
   __shared__ __attribute__((aligned(16))) uint16_t tile_c[2][33 * IT_CW];
   __shared__ __attribute__((aligned(16))) int16_t resi_y[64 * 64];
@@ -1589,6 +1590,31 @@ __global__ __launch_bounds__(IT_NTHR, HEVCRECON_INTRA_MIN_WAVES) void k_intra(co
   const int nit = ci.n_items < IT_MAX_ITEMS ? ci.n_items : IT_MAX_ITEMS;
   uint4 pre_ry = make_uint4(0, 0, 0, 0), pre_item = make_uint4(0, 0, 0, 0);
   uint2 pre_rc = make_uint2(0, 0);
+  // (IPCM units are why an intra picture may need its CTUs staged whole: the transform kernel has already stored them)
+  const bool need_inside = INSIDE && (J.slice_type != 2 || J.has_pcm);
+  constexpr int SPV = 16 / sizeof(pel_t);                // samples per 16-byte vector
+  constexpr int VPR_Y = 64 / SPV, VPR_C = 32 / SPV;      // vectors per luma / chroma row of the CTU
+  constexpr int NV_Y = (64 * VPR_Y + IT_NTHR - 1) / IT_NTHR, NV_C = (2 * 32 * VPR_C + IT_NTHR - 1) / IT_NTHR;
+  uint4 pre_in_y[INSIDE ? NV_Y : 1], pre_in_c[INSIDE ? NV_C : 1];
+  if constexpr (INSIDE) {
+    if (need_inside) {
+      const pel_t *py = (const pel_t *)J.rec[0];
+#pragma unroll
+      for (int k = 0; k < NV_Y; k++) {
+        const int v = tid + k * IT_NTHR, ty = v / VPR_Y, tx = (v % VPR_Y) * SPV;
+        pre_in_y[k] = make_uint4(0, 0, 0, 0);
+        if (v < 64 * VPR_Y && ctux + tx < s.w && ctuy + ty < s.h) pre_in_y[k] = *(const uint4 *)(py + (size_t)(ctuy + ty) * s.stride_y + ctux + tx);
+      }
+#pragma unroll
+      for (int k = 0; k < NV_C; k++) {
+        const int v = tid + k * IT_NTHR;
+        const int c = v / (32 * VPR_C), r = v % (32 * VPR_C), ty = r / VPR_C, tx = (r % VPR_C) * SPV;
+        pre_in_c[k] = make_uint4(0, 0, 0, 0);
+        if (v < 2 * 32 * VPR_C && (ctux >> 1) + tx < s.cw && (ctuy >> 1) + ty < s.ch)
+          pre_in_c[k] = *(const uint4 *)((const pel_t *)J.rec[1 + c] + (size_t)((ctuy >> 1) + ty) * s.stride_c + (ctux >> 1) + tx);
+      }
+    }
+  }
   unsigned pre_lvl = 0;
   static_assert(IT_NTHR == 64 * 64 / 8 && IT_NTHR == 2 * 32 * 32 / 4 && IT_MAX_ITEMS <= IT_NTHR && IT_MAX_ROUNDS <= IT_NTHR,
                 "one residual vector, one block and one round per lane");
@@ -1645,44 +1671,34 @@ __global__ __launch_bounds__(IT_NTHR, HEVCRECON_INTRA_MIN_WAVES) void k_intra(co
   HR_STAMP(1)
 
   // ---- stage the CTU and its top / left borders in LDS ----
-  // An all-intra picture writes every sample of the CTU before reading it, so only the borders are needed.
-  // (IPCM units are the exception: the transform kernel has already stored them)
-  const bool need_inside = J.slice_type != 2 || J.has_pcm;
+  // A picture of intra blocks only writes every sample of the CTU before reading it, so only the borders are needed.
   {
-    // All loads of the staging phase are independent of each other (one round trip to memory in total):
-    // interior rows as 16-byte vectors, the border row and column as single samples.
-    constexpr int VPR_Y = 64 * sizeof(pel_t) / 16;  // 16-byte vectors per luma row of the CTU
-    constexpr int SPV = 16 / sizeof(pel_t);         // samples per vector
-    if (need_inside) {
-      const pel_t *py = (const pel_t *)J.rec[0];
+    // The border loads are independent of each other (one round trip to memory in total); the CTU's own samples,
+    // where needed, are in registers already.
+    if constexpr (INSIDE) {
+      if (need_inside) {
+        // 16 bytes of the picture -> SPV tile samples, two per dword, stored as 8-byte pieces
+        auto put = [](uint16_t *t, const uint4 &qv) {
+          const unsigned w[4] = {qv.x, qv.y, qv.z, qv.w};
+          if constexpr (sizeof(pel_t) == 1) {
 #pragma unroll
-      for (int k = 0; k < (64 * VPR_Y + IT_NTHR - 1) / IT_NTHR; k++) {
-        const int v = tid + k * IT_NTHR, ty = v / VPR_Y, tx = (v % VPR_Y) * SPV;
-        const int gx = ctux + tx, gy = ctuy + ty;
-        if (v < 64 * VPR_Y && gx < s.w && gy < s.h) {
-          const uint4 q = *(const uint4 *)(py + (size_t)gy * s.stride_y + gx);
-          const unsigned w[4] = {q.x, q.y, q.z, q.w};
-          uint16_t *t = &tile_y[(ty + 1) * IT_YW + tx + IT_X0];
-#pragma unroll
-          for (int e = 0; e < SPV; e++)
-            t[e] = sizeof(pel_t) == 1 ? (uint16_t)((w[e >> 2] >> (8 * (e & 3))) & 255) : (uint16_t)((w[e >> 1] >> (16 * (e & 1))) & 65535);
-        }
-      }
-      constexpr int VPR_C = 32 * sizeof(pel_t) / 16;
-#pragma unroll
-      for (int k = 0; k < (2 * 32 * VPR_C + IT_NTHR - 1) / IT_NTHR; k++) {
-        const int v = tid + k * IT_NTHR;
-        if (v < 2 * 32 * VPR_C) {
-          const int c = v / (32 * VPR_C), r = v % (32 * VPR_C), ty = r / VPR_C, tx = (r % VPR_C) * SPV;
-          const int gx = (ctux >> 1) + tx, gy = (ctuy >> 1) + ty;
-          if (gx < s.cw && gy < s.ch) {
-            const uint4 q = *(const uint4 *)((const pel_t *)J.rec[1 + c] + (size_t)gy * s.stride_c + gx);
-            const unsigned w[4] = {q.x, q.y, q.z, q.w};
-            uint16_t *t = &tile_c[c][(ty + 1) * IT_CW + tx + IT_X0];
-#pragma unroll
-            for (int e = 0; e < SPV; e++)
-              t[e] = sizeof(pel_t) == 1 ? (uint16_t)((w[e >> 2] >> (8 * (e & 3))) & 255) : (uint16_t)((w[e >> 1] >> (16 * (e & 1))) & 65535);
+            for (int j = 0; j < 4; j++)
+              *(uint2 *)(t + 4 * j) = make_uint2((w[j] & 0xffu) | ((w[j] & 0xff00u) << 8), ((w[j] >> 16) & 0xffu) | ((w[j] >> 24) << 16));
+          } else {
+            *(uint2 *)t = make_uint2(w[0], w[1]);
+            *(uint2 *)(t + 4) = make_uint2(w[2], w[3]);
           }
+        };
+#pragma unroll
+        for (int k = 0; k < NV_Y; k++) {
+          const int v = tid + k * IT_NTHR, ty = v / VPR_Y, tx = (v % VPR_Y) * SPV;
+          if (v < 64 * VPR_Y && ctux + tx < s.w && ctuy + ty < s.h) put(&tile_y[(ty + 1) * IT_YW + tx + IT_X0], pre_in_y[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < NV_C; k++) {
+          const int v = tid + k * IT_NTHR;
+          const int c = v / (32 * VPR_C), r = v % (32 * VPR_C), ty = r / VPR_C, tx = (r % VPR_C) * SPV;
+          if (v < 2 * 32 * VPR_C && (ctux >> 1) + tx < s.cw && (ctuy >> 1) + ty < s.ch) put(&tile_c[c][(ty + 1) * IT_CW + tx + IT_X0], pre_in_c[k]);
         }
       }
     }
@@ -2495,8 +2511,8 @@ void hr_launch_output(const void *const planes[3], void *dst, const SeqInfo &s, 
   }
 }
 
-void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list, int n_items, int max_parallel, bool dense, unsigned *ticket,
-                     hipStream_t st) {
+void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list, int n_items, int max_parallel, bool dense, bool inside,
+                     unsigned *ticket, hipStream_t st) {
   // No more workgroups than CTUs that can ever be worked on at a time (the largest wave of the batch), and no more
   // than fill the device: a workgroup that has drawn a CTU holds its place on the device while it waits for that
   // CTU's neighbours.  One workgroup per compute unit as a rule: more of them crowd out the kernels of other engine
@@ -2509,10 +2525,18 @@ void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list,
   const int cap = forced > 0 ? forced : dense ? 384 : 256;
   if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
-  if (s.bd_y <= 8 && s.bd_c <= 8)
-    LAUNCH(k_intra<uint8_t>, dim3(grid), dim3(IT_NTHR), st, jobs, s, list, n_items, ticket);
-  else
-    LAUNCH(k_intra<uint16_t>, dim3(grid), dim3(IT_NTHR), st, jobs, s, list, n_items, ticket);
+  const bool wide = s.bd_y > 8 || s.bd_c > 8;
+  if (inside) {
+    if (!wide)
+      LAUNCH((k_intra<uint8_t, true>), dim3(grid), dim3(IT_NTHR), st, jobs, s, list, n_items, ticket);
+    else
+      LAUNCH((k_intra<uint16_t, true>), dim3(grid), dim3(IT_NTHR), st, jobs, s, list, n_items, ticket);
+  } else {
+    if (!wide)
+      LAUNCH((k_intra<uint8_t, false>), dim3(grid), dim3(IT_NTHR), st, jobs, s, list, n_items, ticket);
+    else
+      LAUNCH((k_intra<uint16_t, false>), dim3(grid), dim3(IT_NTHR), st, jobs, s, list, n_items, ticket);
+  }
 }
 
 void hr_launch_md5(const Md5Plane *planes, int n, uint8_t *digests, hipStream_t st) {
