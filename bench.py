@@ -409,7 +409,7 @@ def main():
     frames_total = sharding.sum_over_ranks(npic * S * args.steps, dist, device=red_dev)
     value = frames_total / elapsed
     result = {
-        "metric": "1080p_ra_reconstructed_frames_per_s",
+        "metric": "1080p_ra_reconstructed_frames_per_s" if args.fixture.startswith("randomaccess_main") else "reconstructed_frames_per_s",
         "value": round(value, 2),
         "unit": "frames/s",
         "n_gpus": world,
@@ -421,9 +421,9 @@ def main():
         "vs_baseline": None,
         "dtype": "u8" if sp.bit_depth_luma <= 8 else "u16",
         "data": "synthetic",
-        "config": {"workload": "%dx%d %d-frame RA streams (encoder_randomaccess_main.cfg) of %d different clips, %d independent streams per GPU "
+        "config": {"workload": "%dx%d %d-frame streams (encoder_%s.cfg) of %d different clips, %d independent streams per GPU "
                                "over %d engine contexts, %s, stream-sharded, no collectives"
-                               % (sp.width, sp.height, npic, len(seqs), S, C,
+                               % (sp.width, sp.height, npic, args.fixture.rsplit("_", 1)[0], len(seqs), S, C,
                                   "every stream at its own decoding position" if args.stagger else
                                   "the streams of a context at one decoding position, the contexts %d pictures apart" % (npic // C)),
                    "streams_per_gpu": S, "contexts_per_gpu": C, "frames_per_stream": npic, "clips": len(seqs), "staggered": bool(args.stagger),
