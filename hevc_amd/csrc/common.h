@@ -125,7 +125,7 @@ struct IntraItem {
 
 struct IntraCtu {
   uint32_t item_start; /* first IntraItem of this CTU */
-  uint32_t lvl_start;  /* first entry of this CTU in lvl_counts[] */
+  uint32_t lvl_start;  /* first entry of this CTU in the packer's per-level block counts (host side: statistics) */
   uint16_t n_items;
   uint16_t n_lvl;      /* local dependency levels */
   uint8_t cx, cy;      /* CTU position in CTUs (pictures are at most 8192 samples = 128 CTUs wide and high) */

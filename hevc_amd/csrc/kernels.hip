@@ -1728,7 +1728,7 @@ __global__ __launch_bounds__(IT_NTHR, INSIDE ? 4 : 6) void k_intra(const PicJob 
       }
     }
     // residual of the CTU's coded intra blocks (positions without one hold garbage and are never read), block list
-    // and level counts: fetched above
+    // and rounds: fetched above
     *(uint4 *)&resi_y[(tid >> 3) * 64 + (tid & 7) * 8] = pre_ry;
     *(uint2 *)&resi_c[tid >> 8][((tid & 255) >> 3) * 32 + (tid & 7) * 4] = pre_rc;
     if (tid < nit) *(uint4 *)&items_s[tid] = pre_item;
