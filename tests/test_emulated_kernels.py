@@ -187,6 +187,35 @@ def _heterogeneous_batches_match_their_own_streams(lib, streams, npics, check_st
     eng.close()
 
 
+def _batch_of_intra_pictures_matches_reference(lib, stream, npics):
+    """The pictures of an all-intra stream read no other picture, so all of them can go into ONE
+    hevcrecon_reconstruct_batch call: a batch without a single inter block (the intra kernel's instantiation that
+    stages CTU borders only; with eight pictures or more also the launch with more workgroups).  Every picture is
+    checked against the digests of the reference decoder's own picture."""
+    from hevc_amd import syntax
+
+    seq = load_golden(stream, npics)
+    assert len(seq.pictures) == npics and all(int(p.pic_params.slice_type) == 2 for p in seq.pictures)
+    sp = seq.seq_params
+    bd = [sp.bit_depth_luma, sp.bit_depth_chroma, sp.bit_depth_chroma]
+    eng = engine.Engine(sp, lib=lib)
+    syns = [eng.new_syntax() for _ in range(npics)]
+    pics = [_clone_with_id_offset(p, 64 * i) for i, p in enumerate(seq.pictures)]  # the decoder recycles its picture ids
+    for y, p in zip(syns, pics):
+        y.pack(p)
+    eng.reconstruct_batch(syns, [p.pic_id for p in pics])
+    for p in pics:
+        final = eng.download(p.pic_id)
+        assert [syntax.plane_md5(final[c], bd[c]) for c in range(3)] == p.stage_md5[2], (stream, p.poc)
+    for y in syns:
+        y.close()
+    eng.close()
+
+
+def test_emulated_batch_of_intra_pictures(emu_lib):
+    _batch_of_intra_pictures_matches_reference(emu_lib, "intra_main_416x240", 9)
+
+
 def test_emulated_heterogeneous_batch(emu_lib):
     _heterogeneous_batches_match_their_own_streams(emu_lib, ["lowdelay_P_main", "wpp", "intra_main", "slices"], 3, True)
 

@@ -301,6 +301,16 @@ def test_heterogeneous_batches():
     _heterogeneous_batches_match_their_own_streams(lib, ["randomaccess_he10", "wpb"], None, True)
 
 
+@pytest.mark.parametrize("stream,npics", [("intra_main_416x240", 9), ("intra_main_1920x1080", 16)])
+def test_batch_of_intra_pictures(stream, npics):
+    """All pictures of an all-intra stream in one batch (see the helper): the intra kernel's borders-only instantiation,
+    and the launch with more workgroups that batches of eight intra pictures and more get."""
+    from test_emulated_kernels import _batch_of_intra_pictures_matches_reference
+    from hevc_amd import abi
+
+    _batch_of_intra_pictures_matches_reference(abi.load_library(), stream, npics)
+
+
 def test_picture_copy():
     from test_emulated_kernels import _picture_copy_gives_the_same_picture
     from hevc_amd import abi
