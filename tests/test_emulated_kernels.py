@@ -196,6 +196,7 @@ def _batch_of_intra_pictures_matches_reference(lib, stream, npics):
 
     seq = load_golden(stream, npics)
     assert len(seq.pictures) == npics and all(int(p.pic_params.slice_type) == 2 for p in seq.pictures)
+    npics = len(seq.pictures)
     sp = seq.seq_params
     bd = [sp.bit_depth_luma, sp.bit_depth_chroma, sp.bit_depth_chroma]
     eng = engine.Engine(sp, lib=lib)
@@ -213,7 +214,7 @@ def _batch_of_intra_pictures_matches_reference(lib, stream, npics):
 
 
 def test_emulated_batch_of_intra_pictures(emu_lib):
-    _batch_of_intra_pictures_matches_reference(emu_lib, "intra_main_416x240", 9)
+    _batch_of_intra_pictures_matches_reference(emu_lib, "intra_main_416x240", 4)  # (the GPU suite batches all of them)
 
 
 def test_emulated_heterogeneous_batch(emu_lib):
