@@ -84,6 +84,12 @@ struct McBlk {
 // The intra kernel takes a CTU's blocks in rounds: up to HR_INTRA_ROUND_BLOCKS blocks of one local level, one wave
 // each.  (90 levels and 384 blocks give at most 90 + 384 / 8 rounds.)
 #define HR_INTRA_ROUND_BLOCKS 8
+// A 32x32 block stands in the list this many times (1, 2 or 4), each entry predicting its share of the block's rows:
+// the waves that take the entries each build the block's reference samples for themselves and share no more than
+// that work, so the block's prediction -- the longest chain a round can hold -- is cut without a hand-over.
+#ifndef HR_INTRA_SPLIT32
+#define HR_INTRA_SPLIT32 4
+#endif
 #define HR_INTRA_MAX_ROUNDS 144
 // A round as the kernel reads it: first block (relative to the CTU's first) and number of blocks
 #define IR_BASE_MASK 0x1ff
@@ -116,6 +122,7 @@ struct IntraItem {
 #define IP_FILTER 0x40000 /* bit 18: the block predicts from smoothed samples (TComPattern::getPredictorPtr) */
 #define IP_ANGLE_SHIFT 19 /* 7 bits: intraPredAngle + 32 (angular modes; negative for horizontal modes means the same as for vertical) */
 #define IP_ABS_SHIFT 26   /* 4 bits: |mode - 10| or |mode - 26|, whichever applies (index of the inverse-angle table) */
+#define IP_PART_SHIFT 30  /* 2 bits: which part of a 32x32 block this entry predicts (see HR_INTRA_SPLIT32) */
 
 /* IntraCtu.deps: neighbouring CTUs whose intra blocks this CTU's blocks read (it has to wait for them) */
 #define IC_DEP_LEFT 1

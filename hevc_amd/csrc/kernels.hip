@@ -1401,12 +1401,12 @@ __device__ __forceinline__ IntraBlk intra_blk(const SeqInfo &s, uint16_t *tile_y
 // their position along the direction -- so the angular modes' reference offset and fraction -- and read G + 1
 // neighbouring reference samples; row groups of four load their residual and store their result as 8 bytes.
 // G = 4 for blocks of 16x16 and more (a 16x16 block is one pass of a wave), G = 1 for the small ones, where one
-// sample per lane is the shorter chain.  This call handles groups g_first, g_first + g_step, ...
+// sample per lane is the shorter chain.  This call handles groups g_first, g_first + g_step, ... below ngr.
 template <int G>
-__device__ __forceinline__ void intra_predict(const IntraBlk &B, int g_first, int g_step) {
+__device__ __forceinline__ void intra_predict(const IntraBlk &B, int g_first, int g_step, int ngr) {
   constexpr int LG = G == 4 ? 2 : 0;
   static_assert(G == 4 || G == 1, "groups of four samples or single samples");
-  const int log2n = B.log2n, n = 1 << log2n, ngr = (n * n) >> LG;
+  const int log2n = B.log2n, n = 1 << log2n;
   const int mode = B.mode, maxv = B.maxv, tw = B.tw, rw = B.rw, dcv = B.dcv;
   const uint16_t *cn = B.cn;
   const bool hor = mode >= 2 && mode < 18;
@@ -1770,10 +1770,13 @@ __global__ __launch_bounds__(IT_NTHR, INSIDE ? 4 : 6) void k_intra(const PicJob 
                                          comp ? s.bd_c : s.bd_y, s.strong_intra, ref_s[slot], lane);
         hr_wave_sync();  // the reference samples were written by other lanes of this wave
         const IntraBlk B = intra_blk(s, tile_y, tile_c[0], tile_c[1], resi_y, resi_c[0], resi_c[1], ctux, ctuy, w0, w1, w3, dcv, ref_s[slot], inv_tab);
-        if (log2n >= 4)
-          intra_predict<4>(B, lane, 64);
+        if (log2n == 5) {  // this entry's share of the block's 256 groups
+          const int part = (int)(w3 >> IP_PART_SHIFT), share = 256 / HR_INTRA_SPLIT32;
+          intra_predict<4>(B, part * share + lane, 64, (part + 1) * share);
+        } else if (log2n == 4)
+          intra_predict<4>(B, lane, 64, 64);
         else
-          intra_predict<1>(B, lane, 64);
+          intra_predict<1>(B, lane, 64, 1 << (2 * log2n));
       }
       HR_STAMP(9)
       {

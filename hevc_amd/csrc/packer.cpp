@@ -513,9 +513,13 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
     emit_tu(ctu, comp, z, zcu, x, y, log2n, TU_TO_RESI | ((comp == 0 && log2n == 2) ? TU_DST : 0), NULL);
     it.flags |= IN_HAS_RESI;
   }
-  ctu_items.push_back(it);
-  ctu_item_nb.push_back(nb);
-  ctu_item_lvl.push_back((uint16_t)level);
+  const int parts = log2n == 5 ? HR_INTRA_SPLIT32 : 1;
+  for (int part = 0; part < parts; part++) {
+    it.prep = (uint32_t)part << IP_PART_SHIFT;  // the rest of the word is filled in when the picture closes
+    ctu_items.push_back(it);
+    ctu_item_nb.push_back(nb);
+    ctu_item_lvl.push_back((uint16_t)level);
+  }
 }
 
 void PackedPicture::intra_tus(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy, int zcu, int z, int size, int trdepth, int chroma) {
@@ -600,7 +604,7 @@ bool PackedPicture::finish(const hevcrecon_pic_params *p) {
       intra[i].avail_above &= intra_nb[i].above;
       if (!intra_nb[i].corner) intra[i].flags &= (uint8_t)~IN_CORNER;
     }
-  for (size_t i = 0; i < intra.size(); i++) intra[i].prep = intra_prep(intra[i]);
+  for (size_t i = 0; i < intra.size(); i++) intra[i].prep = intra_prep(intra[i]) | (intra[i].prep & (3u << IP_PART_SHIFT));
   // order the CTUs that hold intra blocks by wave
   int nw = 0;
   for (size_t i = 0; i < ictu_wave.size(); i++) nw = std::max<int>(nw, ictu_wave[i]);
