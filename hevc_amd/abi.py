@@ -145,6 +145,9 @@ EXPORTS = {
     "hevcrecon_picture_download": (C.c_int, [_P, C.c_int, _I16P, _I16P, _I16P, C.c_int, C.c_int]),
     "hevcrecon_picture_download_file": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "hevcrecon_picture_md5_batch": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "hevcrecon_picture_md5_submit": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "hevcrecon_picture_md5_poll": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int), C.c_void_p]),
+    "hevcrecon_picture_md5_wait": (C.c_int, [_P, C.c_int64, C.c_void_p]),
     "hevcrecon_debug_keep_stages": (C.c_int, [_P, C.c_int]),
     "hevcrecon_debug_download_stage": (C.c_int, [_P, C.c_int, _I16P, _I16P, _I16P, C.c_int, C.c_int]),
     "hevcrecon_picture_upload": (C.c_int, [_P, C.c_int, C.c_int, _I16P, _I16P, _I16P, C.c_int, C.c_int]),

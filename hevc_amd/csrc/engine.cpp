@@ -33,6 +33,13 @@ static __device__ __align__(256) unsigned char scratch[HR_SCRATCH_BYTES];
 
 namespace {
 unsigned char *g_scratch_ptr[64];  // per device; guarded by g_copy_mutex
+// Who used the device's fixed work area last, and the event recorded behind that call's last kernel: a call from
+// another context makes its stream wait for it before anything is written to the array.  Guarded by g_copy_mutex.
+struct ScratchUser {
+  hevcrecon_ctx *ctx;
+  hipEvent_t done;
+};
+ScratchUser g_scratch_user[64];
 const size_t kScratchJobBytes = 4096;    // one PicJob
 const size_t kScratchSyncBytes = 61440;  // the intra kernel's scheduling words (ticket counter + one word per CTU)
 const int kMaxPics = 1 << 16;
@@ -94,7 +101,20 @@ struct DevPicture {
   void *p[3] = {nullptr, nullptr, nullptr};
   int poc = 0;
   bool valid = false;
+  int64_t md5_ticket = -1;  // last hevcrecon_picture_md5_submit that reads the picture (-1: none)
 };
+
+// One hevcrecon_picture_md5_submit in flight: descriptors and digests on the device, digests in pinned memory, and
+// the event behind the copy that brings them back.
+struct Md5Slot {
+  int64_t ticket = -1;  // -1: free
+  int n = 0;
+  void *dev = nullptr;
+  uint8_t *host = nullptr;
+  size_t cap = 0;  // pictures the buffers hold
+  hipEvent_t done = nullptr;
+};
+const int kMd5Slots = 64;
 
 struct Interval {
   int kind;
@@ -156,6 +176,11 @@ struct hevcrecon_ctx {
   int longest_intra_wait = 0;         // polls of the longest wait of an intra CTU for a neighbour seen so far (word 8)
   void *dl_host = nullptr;  // pinned staging for downloads / uploads
   void *out_dev = nullptr;  // a picture in file format (hevcrecon_picture_download_file)
+  // hevcrecon_picture_md5_submit: a stream of its own beside the reconstruction kernels, tickets in flight
+  hipStream_t md5_stream = nullptr;
+  hipEvent_t md5_fork = nullptr;  // recorded on the kernels' stream, waited for by md5_stream
+  Md5Slot md5_slots[kMd5Slots];
+  int64_t md5_next = 0;
   size_t out_cap = 0;
   size_t dl_cap = 0;
   bool profiling = false;
@@ -378,6 +403,16 @@ int check_device_errors(hevcrecon_ctx *c) {
   return fail(c, m);
 }
 
+// A picture that a queued hevcrecon_picture_md5_submit still reads must not be overwritten before the hash kernel is
+// done with it: the kernels' stream waits for that ticket's event (nothing is allocated here).
+int wait_for_md5_reader(hevcrecon_ctx *c, DevPicture &p) {
+  if (p.md5_ticket < 0) return 0;
+  Md5Slot &m = c->md5_slots[p.md5_ticket % kMd5Slots];
+  if (m.ticket == p.md5_ticket && m.done) HIPCHK(c, hipStreamWaitEvent(c->stream, m.done, 0));
+  p.md5_ticket = -1;
+  return 0;
+}
+
 // Copy device planes of `p` into int16 host planes.
 int download_planes(hevcrecon_ctx *c, const DevPicture &p, int16_t *y, int16_t *cb, int16_t *cr, int stride_y, int stride_c) {
   const SeqInfo &s = c->si;
@@ -421,6 +456,19 @@ void destroy_context(hevcrecon_ctx *c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->have_copy_streams)
     for (int i = 0; i < kCopyStreams; i++) hipStreamSynchronize(c->copy_stream[i]);
+  if (c->md5_stream) hipStreamSynchronize(c->md5_stream);
+  {  // the fixed work area has no user any more once this context's stream has drained
+    std::lock_guard<std::mutex> lock(g_copy_mutex);
+    if (c->device >= 0 && c->device < 64 && g_scratch_user[c->device].ctx == c) g_scratch_user[c->device] = ScratchUser{nullptr, nullptr};
+  }
+  for (int i = 0; i < kMd5Slots; i++) {
+    Md5Slot &m = c->md5_slots[i];
+    if (m.dev) hipFree(m.dev);
+    if (m.host) hipHostFree(m.host);
+    if (m.done) hipEventDestroy(m.done);
+  }
+  if (c->md5_fork) hipEventDestroy(c->md5_fork);
+  if (c->md5_stream) hipStreamDestroy(c->md5_stream);
   drain_intervals(c);
   for (size_t i = 0; i < c->pics.size(); i++) free_picture(c->pics[i]);
   for (size_t i = 0; i < c->work.size(); i++) free_picture(c->work[i]);
@@ -516,6 +564,7 @@ extern "C" int hevcrecon_sequence_init(hevcrecon_ctx *c, const hevcrecon_seq_par
   if (!seq_params_ok(*sp, why)) return fail(c, why);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->md5_stream) HIPCHK(c, hipStreamSynchronize(c->md5_stream));
   for (size_t i = 0; i < c->pics.size(); i++) free_picture(c->pics[i]);
   for (size_t i = 0; i < c->work.size(); i++) free_picture(c->work[i]);
   for (size_t i = 0; i < c->work_resi.size(); i++) {
@@ -782,11 +831,8 @@ extern "C" int hevcrecon_syntax_stats(const hevcrecon_syntax *s, int64_t out[32]
   out[11] = (int64_t)k.ictu.size();
   out[12] = (int64_t)k.lvl_counts.size();
   out[7] = k.mc_ref_samples;
-  out[8] = k.finished ? k.n_rec4 : (int64_t)k.rec4.size();
-  int64_t intra4 = 0;
-  for (size_t i = 0; i < k.rec4.size(); i++) intra4 += (k.rec4[i].flags & P4_INTRA) ? 1 : 0;
-  if (k.finished) intra4 = k.n_rec4_intra;
-  out[9] = intra4;
+  out[8] = k.n_rec4;
+  out[9] = k.n_rec4_intra;
   out[29] = (int64_t)s->upload_bytes;
   out[30] = (int64_t)k.runs.size();
   out[10] = k.finished ? 1 : 0;
@@ -867,6 +913,8 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
   const SeqInfo &s = c->si;
   PicJob *jh = ws.jobs_host, *jd = ws.jobs_dev;
   if (c->ring_used[ws.slot]) HIPCHK(c, hipEventSynchronize(c->ring_ev[ws.slot]));
+  for (int i = 0; i < n; i++)
+    if (wait_for_md5_reader(c, c->pics[dst_ids[i]])) return 1;
   int max_tu[4] = {0, 0, 0, 0}, max_small_groups = 0, max_levels = 0, max_mct[3] = {0, 0, 0}, max_mcb = 0;
   bool any_deblock = false, any_sao = false, any_wp = false, any_expand = false;
   for (int i = 0; i < n; i++) {
@@ -1192,8 +1240,16 @@ extern "C" int hevcrecon_reconstruct_noalloc(hevcrecon_ctx *c, hevcrecon_syntax 
   ws.work_base[0] = base + off_work;
   ws.resi_base[0] = base + off_resi;
   ws.fixed = true;
+  // Contexts of one GPU share the array: a call orders itself behind the last call of another context (a wait in the
+  // stream, nothing allocated), so that overlapping use from two contexts is serialised instead of corrupting both.
+  std::lock_guard<std::mutex> lock(g_copy_mutex);
+  ScratchUser &u = g_scratch_user[c->device];
+  if (u.ctx && u.ctx != c && u.done) HIPCHK(c, hipStreamWaitEvent(c->stream, u.done, 0));
+  const int64_t batch = c->batch_no;
   if (int rc = reconstruct_core(c, 1, one, &dst_pic_id, ws)) return rc;
   c->ring_pos = (c->ring_pos + 1) % kRing;
+  u.ctx = c;
+  u.done = c->batch_ev[batch % kRing];  // recorded behind the call's last kernel (a later record of the slot is later still)
   return 0;
 }
 
@@ -1217,6 +1273,7 @@ extern "C" int hevcrecon_picture_copy(hevcrecon_ctx *c, int dst_pic_id, int src_
   HIPCHK(c, hipSetDevice(c->device));
   if ((int)c->pics.size() <= dst_pic_id) c->pics.resize(dst_pic_id + 1);
   if (alloc_picture(c, c->pics[dst_pic_id])) return 1;
+  if (wait_for_md5_reader(c, c->pics[dst_pic_id])) return 1;
   HIPCHK(c, hipMemcpyAsync(c->pics[dst_pic_id].base, c->pics[src_pic_id].base, c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
   c->pics[dst_pic_id].valid = true;
   c->pics[dst_pic_id].poc = dst_poc;
@@ -1258,7 +1315,7 @@ extern "C" int hevcrecon_picture_download_file(hevcrecon_ctx *c, int pic_id, int
   HIPCHK(c, hipMemcpyAsync(c->dl_host, c->out_dev, need, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memcpy(out, c->dl_host, need);
-  return 0;
+  return check_device_errors(c);  // a picture reconstructed from a work list a kernel refused is not a result
 }
 
 extern "C" int hevcrecon_picture_md5_batch(hevcrecon_ctx *c, int n, const int *pic_ids, uint8_t *digests) {
@@ -1298,7 +1355,105 @@ extern "C" int hevcrecon_picture_md5_batch(hevcrecon_ctx *c, int n, const int *p
     std::memcpy(digests + 48 * i, dig_host + 16 * i, 16);
     std::memcpy(digests + 48 * i + 16, dig_host + 16 * (n + 2 * i), 32);
   }
+  return check_device_errors(c);
+}
+
+// The same hash without blocking: the kernel runs on a stream of its own behind everything queued on the context so
+// far, beside the reconstruction of later pictures; the digests come back into pinned memory and are collected with
+// hevcrecon_picture_md5_poll / _wait.  A picture that a pending ticket still reads is protected: whatever would
+// overwrite it is ordered behind the hash kernel.
+extern "C" int hevcrecon_picture_md5_submit(hevcrecon_ctx *c, int n, const int *pic_ids, int64_t *ticket) {
+  if (!c || !pic_ids || !ticket) return 1;
+  *ticket = -1;
+  if (n <= 0 || n > HR_MD5_MAX_PICTURES) return fail(c, "number of pictures to digest out of range");
+  for (int i = 0; i < n; i++)
+    if (pic_ids[i] < 0 || pic_ids[i] >= (int)c->pics.size() || !c->pics[pic_ids[i]].valid) return fail(c, "picture is not resident");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!c->md5_stream) {
+    HIPCHK(c, hipStreamCreateWithFlags(&c->md5_stream, hipStreamNonBlocking));
+    HIPCHK(c, hipEventCreateWithFlags(&c->md5_fork, hipEventDisableTiming));
+  }
+  Md5Slot &m = c->md5_slots[c->md5_next % kMd5Slots];
+  if (m.ticket >= 0) return fail(c, "too many picture hashes in flight: collect earlier tickets with hevcrecon_picture_md5_poll or _wait first");
+  const size_t desc_bytes = align_up(sizeof(Md5Plane) * 3 * n, 256), dig_bytes = (size_t)48 * n;
+  if (m.cap < (size_t)n) {
+    if (m.dev) hipFree(m.dev);
+    if (m.host) hipHostFree(m.host);
+    m.dev = nullptr;
+    m.host = nullptr;
+    m.cap = 0;
+    const size_t cap = std::max<size_t>(n, 16);
+    const size_t bytes = align_up(sizeof(Md5Plane) * 3 * cap, 256) + 48 * cap;
+    HIPCHK(c, hipMalloc(&m.dev, bytes));
+    HIPCHK(c, hipHostMalloc((void **)&m.host, bytes));
+    m.cap = cap;
+  }
+  if (!m.done) HIPCHK(c, hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
+  const SeqInfo &s = c->si;
+  const size_t pb = c->pel_bytes;
+  Md5Plane *d = (Md5Plane *)m.host;  // descriptors, then (after the copy back) the digests, in the slot's pinned buffer
+  for (int i = 0; i < n; i++) {
+    const DevPicture &p = c->pics[pic_ids[i]];
+    d[i] = Md5Plane{p.p[0], (uint32_t)(s.w * pb), (uint32_t)s.h, (uint32_t)(s.stride_y * pb), 0};
+    d[n + 2 * i] = Md5Plane{p.p[1], (uint32_t)(s.cw * pb), (uint32_t)s.ch, (uint32_t)(s.stride_c * pb), 0};
+    d[n + 2 * i + 1] = Md5Plane{p.p[2], (uint32_t)(s.cw * pb), (uint32_t)s.ch, (uint32_t)(s.stride_c * pb), 0};
+  }
+  HIPCHK(c, hipEventRecord(c->md5_fork, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->md5_stream, c->md5_fork, 0));
+  uint8_t *dig_dev = (uint8_t *)m.dev + desc_bytes;
+  HIPCHK(c, hipMemcpyAsync(m.dev, d, sizeof(Md5Plane) * 3 * n, hipMemcpyHostToDevice, c->md5_stream));
+  hr_launch_md5((const Md5Plane *)m.dev, 3 * n, dig_dev, c->md5_stream);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(m.host + desc_bytes, dig_dev, dig_bytes, hipMemcpyDeviceToHost, c->md5_stream));
+  HIPCHK(c, hipEventRecord(m.done, c->md5_stream));
+  m.ticket = c->md5_next++;
+  m.n = n;
+  for (int i = 0; i < n; i++) c->pics[pic_ids[i]].md5_ticket = m.ticket;
+  *ticket = m.ticket;
   return 0;
+}
+
+static int md5_collect(hevcrecon_ctx *c, int64_t ticket, bool block, int *done, uint8_t *digests) {
+  if (!c || !digests || ticket < 0) return 1;
+  Md5Slot &m = c->md5_slots[ticket % kMd5Slots];
+  if (m.ticket != ticket) return fail(c, "unknown picture hash ticket (never issued, or collected already)");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (block) {
+    HIPCHK(c, hipEventSynchronize(m.done));
+  } else {
+    const hipError_t e = hipEventQuery(m.done);
+    if (e == hipErrorNotReady) {
+      (void)hipGetLastError();
+      if (done) *done = 0;
+      return 0;
+    }
+    HIPCHK(c, e);
+  }
+  const int n = m.n;
+  const uint8_t *dig_host = m.host + align_up(sizeof(Md5Plane) * 3 * n, 256);
+  for (int i = 0; i < n; i++) {
+    std::memcpy(digests + 48 * i, dig_host + 16 * i, 16);
+    std::memcpy(digests + 48 * i + 16, dig_host + 16 * (n + 2 * i), 32);
+  }
+  m.ticket = -1;
+  if (done) *done = 1;
+  // the kernels that wrote the pictures ran before the hash kernel: their error words are final
+  if (c->error_host) {
+    HIPCHK(c, hipMemcpyAsync(c->error_host, c->error_flag_dev, 64, hipMemcpyDeviceToHost, c->md5_stream));
+    HIPCHK(c, hipStreamSynchronize(c->md5_stream));
+    if (c->error_host[0]) return check_device_errors(c);
+  }
+  return 0;
+}
+
+extern "C" int hevcrecon_picture_md5_poll(hevcrecon_ctx *c, int64_t ticket, int *done, uint8_t *digests) {
+  if (!done) return 1;
+  *done = 0;
+  return md5_collect(c, ticket, false, done, digests);
+}
+
+extern "C" int hevcrecon_picture_md5_wait(hevcrecon_ctx *c, int64_t ticket, uint8_t *digests) {
+  return md5_collect(c, ticket, true, nullptr, digests);
 }
 
 extern "C" int hevcrecon_debug_keep_stages(hevcrecon_ctx *c, int on) {
@@ -1328,6 +1483,7 @@ extern "C" int hevcrecon_picture_upload(hevcrecon_ctx *c, int pic_id, int poc, c
   const size_t pb = c->pel_bytes;
   const size_t ny = (size_t)s.w * s.h * pb, nc = (size_t)s.cw * s.ch * pb;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->md5_stream) HIPCHK(c, hipStreamSynchronize(c->md5_stream));
   if (ensure_staging(c, ny + 2 * nc)) return 1;
   char *h = (char *)c->dl_host;
   const int16_t *src[3] = {y, cb, cr};
@@ -1359,6 +1515,7 @@ extern "C" int hevcrecon_picture_release(hevcrecon_ctx *c, int pic_id) {
   if (pic_id < 0 || pic_id >= (int)c->pics.size()) return 0;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->md5_stream) HIPCHK(c, hipStreamSynchronize(c->md5_stream));
   free_picture(c->pics[pic_id]);
   return 0;
 }
@@ -1369,6 +1526,7 @@ extern "C" int hevcrecon_synchronize(hevcrecon_ctx *c) {
   for (int k = 0; k < kCopyStreams; k++) HIPCHK(c, hipStreamSynchronize(c->copy_stream[k]));
   c->upload_synced = c->upload_no - 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->md5_stream) HIPCHK(c, hipStreamSynchronize(c->md5_stream));
   return check_device_errors(c);
 }
 

@@ -8,6 +8,7 @@
 #include "packer.h"
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 
 namespace {
 
@@ -29,6 +30,42 @@ struct ZScan {
 };
 const ZScan kZ;
 
+// Working records of pictures being packed (2 MB at 1080p): handed out by begin(), given back by finish().  A decoder
+// packs one picture at a time and a host that keeps thousands of packed pictures does not keep thousands of these.
+struct RecPool {
+  std::mutex m;
+  std::vector<std::vector<Part4>> free_list;
+  void take(std::vector<Part4> &v, size_t n) {
+    {
+      std::lock_guard<std::mutex> lock(m);
+      for (size_t i = 0; i < free_list.size(); i++)
+        if (free_list[i].size() == n) {
+          v.swap(free_list[i]);
+          free_list.erase(free_list.begin() + i);
+          return;
+        }
+    }
+    v.assign(n, Part4());
+  }
+  void give(std::vector<Part4> &v) {
+    if (v.empty()) return;
+    std::lock_guard<std::mutex> lock(m);
+    if (free_list.size() < 8) {
+      free_list.emplace_back();
+      free_list.back().swap(v);
+    }
+    std::vector<Part4>().swap(v);
+  }
+};
+RecPool g_rec_pool;
+
+inline bool same_record(const Part4 &a, const Part4 &b) {
+  uint64_t x[2], y[2];
+  std::memcpy(x, &a, 16);
+  std::memcpy(y, &b, 16);
+  return x[0] == y[0] && x[1] == y[1];
+}
+
 inline int16_t sat16(int32_t v) { return (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
 inline int16_t sat16(int16_t v) { return v; }
 inline int ilog2(int v) {
@@ -41,10 +78,14 @@ inline int ilog2(int v) {
 
 void PackedPicture::begin(const SeqInfo &s) {
   seq = s;
-  rec4.assign((size_t)s.uw * s.uh, Part4());
-  std::memset(rec4.data(), 0, rec4.size() * sizeof(Part4));
+  // per CTU, z-order inside (the order the CTUs' partitions arrive in): every record inside the picture is written
+  // by add_ctu before anything reads it; CTUs that reach over the picture's edge are cleared there first
+  if (rec4.size() != (size_t)s.ctus_w * s.ctus_h * 256) {
+    g_rec_pool.give(rec4);
+    g_rec_pool.take(rec4, (size_t)s.ctus_w * s.ctus_h * 256);
+  }
   for (int i = 0; i < 4; i++) tu[i].clear();
-  coeff.clear();
+  coeff_len = 0;
   coded_coeffs = 0;
   intra.clear();
   intra_nb.clear();
@@ -55,13 +96,12 @@ void PackedPicture::begin(const SeqInfo &s) {
   wave_off.clear();
   ctu_wave.assign((size_t)s.ctus_w * s.ctus_h, 0);
   sao.assign((size_t)s.ctus_w * s.ctus_h * 3, SaoCtu());
-  lvl_y.assign((size_t)s.uw * s.uh, 0);
-  lvl_c.assign((size_t)s.uw * s.uh, 0);
   use_scaling = false;
   use_wp = false;
   has_bypass = false;
   has_pcm = false;
-  n_rec4 = n_rec4_intra = 0;
+  n_rec4 = (int64_t)s.uw * s.uh;
+  n_rec4_intra = 0;
   mc_ref_samples = 0;
   max_ref_idx[0] = max_ref_idx[1] = -1;
   inter_without_ref = false;
@@ -69,6 +109,7 @@ void PackedPicture::begin(const SeqInfo &s) {
   ctu_order.assign((size_t)s.ctus_w * s.ctus_h, -1);
   ctu_tile.assign((size_t)s.ctus_w * s.ctus_h, 0);
   slices.clear();
+  ctu_in_two_slices = false;
   ctu_slice.assign((size_t)s.ctus_w * s.ctus_h, 0);
   ctu_info.clear();
   finished = false;
@@ -76,8 +117,8 @@ void PackedPicture::begin(const SeqInfo &s) {
 }
 
 bool PackedPicture::set_slices(int n, const hevcrecon_slice_params *sl) {
-  if (finished || next_ctu != 0) {
-    error = "the slice table must be set after hevcrecon_syntax_begin and before the first CTU";
+  if (finished) {
+    error = "the slice table must be set between hevcrecon_syntax_begin and hevcrecon_syntax_finish";
     return false;
   }
   if (n < 0 || (n > 0 && !sl)) {
@@ -111,6 +152,17 @@ const hevcrecon_slice_params *PackedPicture::slice_at(uint32_t start) const {
 // boundaries, and no uncrossed tile boundary lies on the sides of the CTU it is reached over.
 bool PackedPicture::build_ctu_info() {
   ctu_info.clear();
+  if (!slices.empty()) {
+    if (ctu_in_two_slices) {
+      error = "a slice table needs slices that end at CTU boundaries";
+      return false;
+    }
+    for (size_t a = 0; a < ctu_slice.size(); a++)
+      if (!slice_at(ctu_slice[a])) {
+        error = "CTU of a slice that is not in the slice table";
+        return false;
+      }
+  }
   if (slices.empty() && !pp.no_loop_filter_across_tiles) return true;
   const int W = seq.ctus_w, H = seq.ctus_h;
   ctu_info.resize((size_t)W * H);
@@ -172,6 +224,10 @@ bool PackedPicture::build_ctu_info() {
 
 // Position in coding order of the 4x4 unit (ux, uy): CTUs in the order they were added (raster, or tile scan),
 // z-order inside.  Units of CTUs that have not been added yet come after everything.
+const Part4 &PackedPicture::unit(int ux, int uy) const {
+  return rec4[((size_t)(uy >> 4) * seq.ctus_w + (ux >> 4)) * 256 + kZ.z[uy & 15][ux & 15]];
+}
+
 int PackedPicture::coding_order(int ux, int uy) const {
   const int o = ctu_order[(size_t)(uy >> 4) * seq.ctus_w + (ux >> 4)];
   return o < 0 ? 0x7fffffff : o * 256 + kZ.z[uy & 15][ux & 15];
@@ -187,18 +243,15 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
   ctu_order[addr] = next_ctu++;
   ctu_tile[addr] = ctu->tile_id;
   ctu_slice[addr] = ctu->slice_start ? ctu->slice_start[0] : 0;
-  if (!slices.empty()) {
-    // per-slice parameters are kept per CTU: every partition inside the picture has to belong to the same slice
+  if (ctu->slice_start) {
+    // per-slice parameters are kept per CTU: should a slice table arrive (any time before the picture closes), every
+    // partition of the CTU inside the picture has to belong to the same slice
     const int cx0 = (addr % seq.ctus_w) * 16, cy0 = (addr / seq.ctus_w) * 16;
-    for (int z = 0; z < 256 && ctu->slice_start; z++)
-      if (cx0 + kZ.x[z] < seq.uw && cy0 + kZ.y[z] < seq.uh && ctu->slice_start[z] != ctu_slice[addr]) {
-        error = "a slice table needs slices that end at CTU boundaries";
-        return false;
+    for (int z = 1; z < 256; z++)
+      if (ctu->slice_start[z] != ctu_slice[addr] && cx0 + kZ.x[z] < seq.uw && cy0 + kZ.y[z] < seq.uh) {
+        ctu_in_two_slices = true;
+        break;
       }
-    if (!slice_at(ctu_slice[addr])) {
-      error = "CTU of a slice that is not in the slice table";
-      return false;
-    }
   }
   for (int c = 0; c < 3; c++) {
     // what the SAO kernel's offset table holds in a byte: types -1..4, offsets of at most 31 in magnitude (the
@@ -220,6 +273,9 @@ bool PackedPicture::add_ctu(int addr, const hevcrecon_ctu_syntax *ctu) {
   ctu_dep_wave = 0;
   ctu_dep_mask = 0;
   const int cx = addr % seq.ctus_w, cy = addr / seq.ctus_w;
+  cur_rec = &rec4[(size_t)addr * 256];
+  if (cx * 64 + 64 > seq.w || cy * 64 + 64 > seq.h) std::memset(cur_rec, 0, 256 * sizeof(Part4));  // units outside the picture stay invalid
+  ctu_has_intra = false;
   walk_cu(ctu, cx * 64, cy * 64, 0, 0);
   if (!error.empty()) return false;
   if (!ctu_items.empty()) {
@@ -294,35 +350,49 @@ void PackedPicture::walk_cu(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy,
   const bool intra = ctu->pred_mode[z] == 1;
   // values that index tables on the device are checked on the way (a parser bug must not become a stray access):
   // the QP range of TComDataCU::setQPSubParts is -QpBDOffset .. 51
-  for (int zz = z; zz < z + np; zz++)
-    if (ctu->qp[zz] < -6 * (seq.bd_y - 8) || ctu->qp[zz] > 51) {
-      error = "QP out of range";
-      return;
-    }
+  const int qp_min = -6 * (seq.bd_y - 8);
+  bool qp_ok = true;
+  for (int zz = z; zz < z + np; zz++) qp_ok = qp_ok && ctu->qp[zz] >= qp_min && ctu->qp[zz] <= 51;
+  if (!qp_ok) {
+    error = "QP out of range";
+    return;
+  }
   const bool pcm = intra && ctu->ipcm && ctu->ipcm[z];
   // TComLoopFilter::xEdgeFilterLuma (TLibCommon/TComLoopFilter.cpp:633-641) and xPCMCURestoration
   // (TLibCommon/TComSampleAdaptiveOffset.cpp:1435): lossless units always, IPCM units when the SPS says so
   const bool unfiltered = (ctu->transquant_bypass && ctu->transquant_bypass[z]) || (pcm && seq.pcm_lf_disable);
+  const uint8_t cu_flags = (uint8_t)((unfiltered ? P4_BYPASS : 0) | (pcm ? P4_IPCM : 0));
+  const uint8_t *cu_depth = ctu->depth, *tr_idx = ctu->tr_idx, *cbf_y = ctu->cbf[0];
+  const int8_t *pred_mode = ctu->pred_mode, *part_size = ctu->part_size, *qp = ctu->qp, *ref0 = ctu->ref_idx[0], *ref1 = ctu->ref_idx[1];
+  const int16_t *mv0 = ctu->mv[0], *mv1 = ctu->mv[1];
+  Part4 *out = cur_rec;
+  int nref_units = 0, max0 = max_ref_idx[0], max1 = max_ref_idx[1];
   for (int zz = z; zz < z + np; zz++) {
-    const int ux = (ctux >> 2) + kZ.x[zz], uy = (ctuy >> 2) + kZ.y[zz];
-    Part4 &p = rec4[(size_t)uy * seq.uw + ux];
-    p.flags = (uint8_t)((ctu->depth[zz] & P4_DEPTH_MASK) | (ctu->pred_mode[zz] == 1 ? P4_INTRA : 0) |
-                        ((ctu->part_size[zz] & 7) << P4_PARTSIZE_SHIFT) |
-                        (unfiltered ? P4_BYPASS : 0) | (pcm ? P4_IPCM : 0));
-    p.tu = (uint8_t)((ctu->tr_idx[zz] & P4_TRIDX_MASK) | (((ctu->cbf[0][zz] >> ctu->tr_idx[zz]) & 1) ? P4_CBF_Y : 0) | P4_VALID);
-    p.qp = ctu->qp[zz];
-    for (int l = 0; l < 2; l++) {
-      p.ref_idx[l] = ctu->ref_idx[l][zz];
-      p.mv[l][0] = ctu->mv[l][2 * zz];
-      p.mv[l][1] = ctu->mv[l][2 * zz + 1];
-    }
+    Part4 p;
+    p.flags = (uint8_t)((cu_depth[zz] & P4_DEPTH_MASK) | (pred_mode[zz] == 1 ? P4_INTRA : 0) | ((part_size[zz] & 7) << P4_PARTSIZE_SHIFT) | cu_flags);
+    p.tu = (uint8_t)((tr_idx[zz] & P4_TRIDX_MASK) | (((cbf_y[zz] >> tr_idx[zz]) & 1) ? P4_CBF_Y : 0) | P4_VALID);
+    p.qp = qp[zz];
+    p.pad = 0;
+    p.ref_idx[0] = ref0[zz];
+    p.ref_idx[1] = ref1[zz];
+    p.pad2[0] = p.pad2[1] = 0;
+    p.mv[0][0] = mv0[2 * zz];
+    p.mv[0][1] = mv0[2 * zz + 1];
+    p.mv[1][0] = mv1[2 * zz];
+    p.mv[1][1] = mv1[2 * zz + 1];
+    out[zz] = p;
     if (!intra) {
-      int nref = (p.ref_idx[0] >= 0) + (p.ref_idx[1] >= 0);
-      mc_ref_samples += 24 * nref;  // 16 luma + 2 x 4 chroma samples per reference read
+      const int nref = (p.ref_idx[0] >= 0) + (p.ref_idx[1] >= 0);
+      nref_units += nref;
       if (nref == 0) inter_without_ref = true;
-      for (int l = 0; l < 2; l++) max_ref_idx[l] = std::max<int>(max_ref_idx[l], p.ref_idx[l]);
+      max0 = p.ref_idx[0] > max0 ? p.ref_idx[0] : max0;
+      max1 = p.ref_idx[1] > max1 ? p.ref_idx[1] : max1;
     }
   }
+  mc_ref_samples += 24 * (int64_t)nref_units;  // 16 luma + 2 x 4 chroma samples per reference read
+  max_ref_idx[0] = max0;
+  max_ref_idx[1] = max1;
+  if (intra) n_rec4_intra += np;
   if (unfiltered) has_bypass = true;
   if (pcm) {
     // TDecCu::xReconPCM (TLibDecoder/TDecCu.cpp:845-871): no prediction, no residual; the samples travel in the
@@ -363,17 +433,26 @@ void PackedPicture::walk_cu(const hevcrecon_ctu_syntax *ctu, int ctux, int ctuy,
 // loses nothing because de-quantisation clips its input to 16 bits first: TLibCommon/TComTrQuant.cpp:1181).
 // Returns the index of the block's header word.
 template <typename T> uint32_t PackedPicture::append_block(const T *src, int nn) {
-  const size_t off = coeff.size();
-  coeff.push_back(0);
+  // (the vector is kept larger than what has been written, coeff_len, so that appending neither checks capacity nor
+  // clears memory per coefficient; finish() cuts it to size)
+  const size_t off = coeff_len;
+  if (coeff.size() < off + 1 + (size_t)nn) coeff.resize(std::max(coeff.size() * 2, off + 1 + (size_t)nn + 4096));
+  uint32_t *dst = coeff.data() + off + 1;
   uint32_t count = 0;
-  for (int i = 0; i < nn; i++) {
-    const int16_t v = sat16(src[i]);
-    if (v) {
-      coeff.push_back((uint32_t)i | ((uint32_t)(uint16_t)v << 16));
-      count++;
+  // most coefficients of a coded block are zero: 16 bytes of zeros at a time are skipped (nn is a multiple of 16)
+  constexpr int G = 16 / (int)sizeof(T);
+  for (int i = 0; i < nn; i += G) {
+    uint64_t w[2];
+    std::memcpy(w, src + i, 16);
+    if (!(w[0] | w[1])) continue;
+    for (int k = i; k < i + G; k++) {
+      const int16_t v = sat16(src[k]);
+      dst[count] = (uint32_t)k | ((uint32_t)(uint16_t)v << 16);
+      count += v != 0;
     }
   }
   coeff[off] = count;
+  coeff_len = off + 1 + count;
   coded_coeffs += nn;
   return (uint32_t)off;
 }
@@ -433,7 +512,11 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
   const int us = 4 >> sh;           // samples per availability unit in this plane
   const int nu = n / us;            // units per block side
   const int ux0 = (x << sh) >> 2, uy0 = (y << sh) >> 2;
-  std::vector<uint16_t> &lvl = comp ? lvl_c : lvl_y;
+  if (!ctu_has_intra) {  // the level maps cover one CTU: cleared when its first intra block arrives
+    std::memset(ctu_lvl, 0, sizeof(ctu_lvl));
+    ctu_has_intra = true;
+  }
+  uint16_t *lvl = ctu_lvl[comp ? 1 : 0];
   const int cur = coding_order(ux0, uy0);
   // A neighbouring unit can be used iff it is inside the picture and precedes this block in coding order
   // (TComPattern::is*Available over TComDataCU::getPU*, TLibCommon/TComPattern.cpp:653-830,
@@ -454,11 +537,11 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
     if ((o >> 8) == (cur >> 8)) return true;
     return o >= slice_start && ctu_tile[(size_t)(uy >> 4) * seq.ctus_w + (ux >> 4)] == my_tile;
   };
-  auto is_intra = [&](int ux, int uy) -> bool { return (rec4[(size_t)uy * seq.uw + ux].flags & P4_INTRA) != 0; };
+  auto is_intra = [&](int ux, int uy) -> bool { return (unit(ux, uy).flags & P4_INTRA) != 0; };
   IntraNeighbours nb = {0, 0, 0};
   auto level_at = [&](int ux, int uy) -> int {
-    if ((ux >> 4) == my_cx && (uy >> 4) == my_cy) return lvl[(size_t)uy * seq.uw + ux];
-    if (rec4[(size_t)uy * seq.uw + ux].flags & P4_INTRA) {
+    if ((ux >> 4) == my_cx && (uy >> 4) == my_cy) return lvl[(uy & 15) * 16 + (ux & 15)];
+    if (unit(ux, uy).flags & P4_INTRA) {
       ctu_dep_wave = std::max<int>(ctu_dep_wave, ctu_wave[(size_t)(uy >> 4) * seq.ctus_w + (ux >> 4)]);
       // neighbours of a block lie in the CTU to the left, above-left, above or above-right of its own
       const int dx = (ux >> 4) - my_cx, dy = (uy >> 4) - my_cy;
@@ -493,7 +576,7 @@ void PackedPicture::emit_intra(const hevcrecon_ctu_syntax *ctu, int comp, int z,
   level += 1;
   if (comp < 2)  // Cb and Cr share one map; Cr arrives right after Cb with identical geometry
     for (int j = 0; j < nu; j++)
-      for (int i = 0; i < nu; i++) lvl[(size_t)(uy0 + j) * seq.uw + ux0 + i] = (uint16_t)level;
+      for (int i = 0; i < nu; i++) lvl[((uy0 + j) & 15) * 16 + ((ux0 + i) & 15)] = (uint16_t)level;
   if (mode < 0 || mode > 34 || log2n < 2 || log2n > 5) {
     error = mode < 0 || mode > 34 ? "intra prediction mode out of range" : "transform block size out of range";
     return;
@@ -621,17 +704,13 @@ bool PackedPicture::finish(const hevcrecon_pic_params *p) {
   std::vector<int32_t> cursor(wave_off.begin(), wave_off.end());
   for (size_t i = 0; i < ictu.size(); i++) sorted[cursor[ictu_wave[i] - 1]++] = ictu[i];
   ictu.swap(sorted);
+  coeff.resize(coeff_len);
   if (!build_ctu_info()) return false;
-  build_mc_lists();
   build_runs();
-  n_rec4 = (int64_t)rec4.size();
-  n_rec4_intra = 0;
-  for (size_t i = 0; i < rec4.size(); i++) n_rec4_intra += (rec4[i].flags & P4_INTRA) ? 1 : 0;
-  // The per-unit working arrays (2.6 MB at 1080p) are not needed any more; a host that keeps thousands of packed
-  // pictures around should not pay for them.
-  std::vector<Part4>().swap(rec4);
-  std::vector<uint16_t>().swap(lvl_y);
-  std::vector<uint16_t>().swap(lvl_c);
+  build_mc_lists();
+  // The per-unit working records (2 MB at 1080p) are not needed any more: they go back to the pool, so that a host
+  // that keeps thousands of packed pictures around does not pay for them.
+  g_rec_pool.give(rec4);
   finished = true;
   return true;
 }
@@ -647,43 +726,94 @@ namespace {
 enum { MC_NONE, MC_UNIFORM, MC_MIXED };
 }
 
-int PackedPicture::classify_mc(int x0, int y0, int size, McTile *out) const {
-  bool any_inter = false, uniform = true, have = false;
+// What one motion record predicts with: the lists in use after the identical-motion shortcut, and the vectors as
+// they are (the caller clips them, or knows that clipping changes nothing).  False for an inter record without any
+// reference.
+bool PackedPicture::mc_of_record(const Part4 &p, McTile *t) const {
+  bool use[2] = {p.ref_idx[0] >= 0, p.ref_idx[1] >= 0};
+  if (use[0] && use[1] && pp.slice_type == 0 && !use_wp && p.ref_idx[0] < HR_MAX_REFS && p.ref_idx[1] < HR_MAX_REFS &&
+      pp.ref_poc[0][p.ref_idx[0]] == pp.ref_poc[1][p.ref_idx[1]] && p.mv[0][0] == p.mv[1][0] && p.mv[0][1] == p.mv[1][1])
+    use[1] = false;
+  if (!use[0] && !use[1]) return false;
+  std::memset(t, 0, sizeof(*t));
+  for (int l = 0; l < 2; l++) {
+    t->ref[l] = use[l] ? p.ref_idx[l] : (int8_t)-1;
+    if (use[l]) {
+      t->mv[l][0] = p.mv[l][0];
+      t->mv[l][1] = p.mv[l][1];
+    }
+  }
+  return true;
+}
+
+// Classification of the square region of `size` luma samples at (x0, y0): units z0 .. z0 + n - 1 of CTU `addr`.
+// The runs of the CTU stand for its units (a run is a stretch of identical records); when a vector could be changed
+// by TComDataCU::clipMv somewhere in the CTU the units are looked at one by one instead, each with the clipping range
+// of its own coding unit.
+int PackedPicture::classify_mc(int addr, int x0, int y0, int size, McTile *out) const {
+  const int n = (size >> 2) * (size >> 2);
+  const int z0 = kZ.z[(y0 >> 2) & 15][(x0 >> 2) & 15];
+  const int ctux = x0 & ~63, ctuy = y0 & ~63;
+  // a vector inside this range is left alone by clipMv for every coding-unit origin of the CTU
+  const int hlo = (-64 - 8 - ctux + 1) * 4, hhi = (seq.w + 8 - (ctux + 60) - 1) * 4;
+  const int vlo = (-64 - 8 - ctuy + 1) * 4, vhi = (seq.h + 8 - (ctuy + 60) - 1) * 4;
+  bool any_inter = false, uniform = true, have = false, by_unit = false;
   McTile first;
   std::memset(&first, 0, sizeof(first));
-  const int ux1 = std::min((x0 + size) >> 2, seq.uw), uy1 = std::min((y0 + size) >> 2, seq.uh);
-  for (int uy = y0 >> 2; uy < uy1; uy++)
-    for (int ux = x0 >> 2; ux < ux1; ux++) {
-      const Part4 &p = rec4[(size_t)uy * seq.uw + ux];
+  for (uint32_t r = ctu_run_off[addr]; r < ctu_run_off[addr + 1] && !by_unit; r++) {
+    const Part4 &p = runs[r];
+    if (p.pad + p.pad2[0] < z0) continue;
+    if (p.pad >= z0 + n) break;
+    if (p.flags & P4_INTRA) {
+      uniform = false;
+      continue;
+    }
+    any_inter = true;
+    if (!uniform) continue;
+    McTile t;
+    if (!mc_of_record(p, &t)) {
+      uniform = false;
+      continue;
+    }
+    for (int l = 0; l < 2; l++)
+      if (t.ref[l] >= 0 && (t.mv[l][0] < hlo || t.mv[l][0] > hhi || t.mv[l][1] < vlo || t.mv[l][1] > vhi)) by_unit = true;
+    t.x = (uint16_t)x0;
+    t.y = (uint16_t)y0;
+    if (!have) {
+      first = t;
+      have = true;
+    } else if (std::memcmp(&first, &t, sizeof(t)) != 0) {
+      uniform = false;
+    }
+  }
+  if (by_unit) {
+    any_inter = false, uniform = true, have = false;
+    const Part4 *rec = &rec4[(size_t)addr * 256];
+    for (int z = z0; z < z0 + n; z++) {
+      const Part4 &p = rec[z];
+      if (!(p.tu & P4_VALID)) continue;
       if (p.flags & P4_INTRA) {
         uniform = false;
         continue;
       }
       any_inter = true;
       if (!uniform) continue;
-      const int cusize = 64 >> (p.flags & P4_DEPTH_MASK);
-      const int cux = (ux * 4) & ~(cusize - 1), cuy = (uy * 4) & ~(cusize - 1);
-      const int hmax = (seq.w + 8 - cux - 1) * 4, hmin = (-64 - 8 - cux + 1) * 4;
-      const int vmax = (seq.h + 8 - cuy - 1) * 4, vmin = (-64 - 8 - cuy + 1) * 4;
-      bool use[2] = {p.ref_idx[0] >= 0, p.ref_idx[1] >= 0};
-      if (use[0] && use[1] && pp.slice_type == 0 && !use_wp && p.ref_idx[0] < HR_MAX_REFS && p.ref_idx[1] < HR_MAX_REFS &&
-          pp.ref_poc[0][p.ref_idx[0]] == pp.ref_poc[1][p.ref_idx[1]] && p.mv[0][0] == p.mv[1][0] && p.mv[0][1] == p.mv[1][1])
-        use[1] = false;
-      if (!use[0] && !use[1]) {
+      McTile t;
+      if (!mc_of_record(p, &t)) {
         uniform = false;
         continue;
       }
-      McTile t;
-      std::memset(&t, 0, sizeof(t));
+      const int cusize = 64 >> (p.flags & P4_DEPTH_MASK);
+      const int cux = (ctux + 4 * kZ.x[z]) & ~(cusize - 1), cuy = (ctuy + 4 * kZ.y[z]) & ~(cusize - 1);
+      const int hmax = (seq.w + 8 - cux - 1) * 4, hmin = (-64 - 8 - cux + 1) * 4;
+      const int vmax = (seq.h + 8 - cuy - 1) * 4, vmin = (-64 - 8 - cuy + 1) * 4;
+      for (int l = 0; l < 2; l++)
+        if (t.ref[l] >= 0) {
+          t.mv[l][0] = (int16_t)std::min(hmax, std::max(hmin, (int)t.mv[l][0]));
+          t.mv[l][1] = (int16_t)std::min(vmax, std::max(vmin, (int)t.mv[l][1]));
+        }
       t.x = (uint16_t)x0;
       t.y = (uint16_t)y0;
-      for (int l = 0; l < 2; l++) {
-        t.ref[l] = use[l] ? p.ref_idx[l] : (int8_t)-1;
-        if (use[l]) {
-          t.mv[l][0] = (int16_t)std::min(hmax, std::max(hmin, (int)p.mv[l][0]));
-          t.mv[l][1] = (int16_t)std::min(vmax, std::max(vmin, (int)p.mv[l][1]));
-        }
-      }
       if (!have) {
         first = t;
         have = true;
@@ -691,6 +821,7 @@ int PackedPicture::classify_mc(int x0, int y0, int size, McTile *out) const {
         uniform = false;
       }
     }
+  }
   if (!any_inter) return MC_NONE;
   if (uniform && have) {
     *out = first;
@@ -699,11 +830,11 @@ int PackedPicture::classify_mc(int x0, int y0, int size, McTile *out) const {
   return MC_MIXED;
 }
 
-void PackedPicture::split_mc(int x0, int y0, int level) {
+void PackedPicture::split_mc(int addr, int x0, int y0, int level) {
   if (x0 >= seq.w || y0 >= seq.h) return;
   const int size = 64 >> level;
   McTile t;
-  const int kind = classify_mc(x0, y0, size, &t);
+  const int kind = classify_mc(addr, x0, y0, size, &t);
   if (kind == MC_NONE) return;
   if (kind == MC_UNIFORM) {
     mc_tile[level].push_back(t);
@@ -717,7 +848,7 @@ void PackedPicture::split_mc(int x0, int y0, int level) {
     return;
   }
   const int h = size >> 1;
-  for (int q = 0; q < 4; q++) split_mc(x0 + (q & 1) * h, y0 + (q >> 1) * h, level + 1);
+  for (int q = 0; q < 4; q++) split_mc(addr, x0 + (q & 1) * h, y0 + (q >> 1) * h, level + 1);
 }
 
 void PackedPicture::build_mc_lists() {
@@ -725,38 +856,31 @@ void PackedPicture::build_mc_lists() {
   mc_blk.clear();
   if (pp.slice_type == 2) return;
   for (int cy = 0; cy < seq.ctus_h; cy++)
-    for (int cx = 0; cx < seq.ctus_w; cx++) split_mc(cx * 64, cy * 64, 0);
+    for (int cx = 0; cx < seq.ctus_w; cx++) split_mc(cy * seq.ctus_w + cx, cx * 64, cy * 64, 0);
 }
 
+// rec4 as it crosses the host link: per CTU (raster order), runs of identical records along its z-order.
 void PackedPicture::build_runs() {
   runs.clear();
   ctu_run_off.assign((size_t)seq.ctus_w * seq.ctus_h + 1, 0);
   for (int cy = 0; cy < seq.ctus_h; cy++)
     for (int cx = 0; cx < seq.ctus_w; cx++) {
-      ctu_run_off[(size_t)cy * seq.ctus_w + cx] = (uint32_t)runs.size();
-      bool open = false;  // the last run can still grow (its successor in z-order is the next unit visited)
-      for (int z = 0; z < 256; z++) {
-        const int ux = cx * 16 + kZ.x[z], uy = cy * 16 + kZ.y[z];
-        if (ux >= seq.uw || uy >= seq.uh) {
-          open = false;
+      const int addr = cy * seq.ctus_w + cx;
+      ctu_run_off[addr] = (uint32_t)runs.size();
+      const Part4 *rec = &rec4[(size_t)addr * 256];
+      int z = 0;
+      while (z < 256) {
+        if (!(rec[z].tu & P4_VALID)) {  // outside the picture
+          z++;
           continue;
         }
-        const Part4 &p = rec4[(size_t)uy * seq.uw + ux];
-        if (open) {
-          Part4 &r = runs.back();
-          Part4 probe = r;
-          probe.pad = 0;
-          probe.pad2[0] = 0;
-          if (std::memcmp(&probe, &p, sizeof(Part4)) == 0) {
-            r.pad2[0]++;
-            continue;
-          }
-        }
-        Part4 r = p;
+        int e = z + 1;
+        while (e < 256 && same_record(rec[e], rec[z])) e++;
+        Part4 r = rec[z];
         r.pad = (uint8_t)z;
-        r.pad2[0] = 0;
+        r.pad2[0] = (uint8_t)(e - z - 1);
         runs.push_back(r);
-        open = true;
+        z = e;
       }
     }
   ctu_run_off.back() = (uint32_t)runs.size();

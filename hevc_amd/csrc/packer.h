@@ -12,12 +12,15 @@
 struct PackedPicture {
   SeqInfo seq;
   hevcrecon_pic_params pp;
-  std::vector<Part4> rec4;          // working copy while the picture is packed; released by finish() (the runs carry it on)
-  int64_t n_rec4, n_rec4_intra;     // records inside the picture, and how many of them are intra
+  // Working records while the picture is packed: per CTU (raster address), z-order inside, 256 each; taken from a
+  // pool by begin() and given back by finish() (the runs carry the records on)
+  std::vector<Part4> rec4;
+  int64_t n_rec4, n_rec4_intra;     // 4x4 units of the picture (the device's raster array), and how many of them are intra
   std::vector<TuItem> tu[4];
   // Coded coefficients, sparse: per transform block one header word (number of non-zero coefficients) followed by
   // that many words (position inside the block, raster) | (value << 16)
   std::vector<uint32_t> coeff;
+  size_t coeff_len;  // words written so far while the picture is packed (the vector may be larger until finish())
   int64_t coded_coeffs;  // coefficients of all coded blocks, zeros included (the figure the algorithmic bytes use)
   template <typename T> uint32_t append_block(const T *src, int nn);
   std::vector<IntraItem> intra;     // grouped by CTU, by local level inside a CTU
@@ -26,11 +29,12 @@ struct PackedPicture {
   std::vector<uint16_t> rounds;     // per CTU: the rounds the intra kernel takes its blocks in (IR_*)
   std::vector<int32_t> wave_off;    // n_waves + 1 offsets into ictu
   std::vector<SaoCtu> sao;
-  // Slices that differ in their parameters or are not filtered across (set before the first CTU; empty: the picture
+  // Slices that differ in their parameters or are not filtered across (set any time before finish(); empty: the picture
   // parameters hold for every slice), the slice every CTU belongs to (its start address), and what finish() derives
   // from both and from the tiles for the kernels (empty when every boundary is crossed with one set of parameters)
   std::vector<hevcrecon_slice_params> slices;
   std::vector<uint32_t> ctu_slice;
+  bool ctu_in_two_slices;  // some CTU holds partitions of more than one slice (refused when a slice table arrives)
   std::vector<CtuInfo> ctu_info;
   bool set_slices(int n, const hevcrecon_slice_params *sl);
   std::vector<McTile> mc_tile[3];   // filled by finish(): 64x64 / 32x32 / 16x16 regions predicted as one block
@@ -66,7 +70,9 @@ struct PackedPicture {
     uint8_t corner;
   };
   std::vector<IntraNeighbours> ctu_item_nb, intra_nb;  // of ctu_items / of intra (same indices)
-  std::vector<uint16_t> lvl_y, lvl_c; // per 4x4 unit: local level of the intra block covering it (0 = none)
+  uint16_t ctu_lvl[2][256];           // per 4x4 unit of the CTU being added (16 x 16, luma / chroma): local level of the intra block covering it (0 = none)
+  bool ctu_has_intra;                 // ctu_lvl has been cleared for this CTU
+  Part4 *cur_rec;                     // records of the CTU being added
   std::vector<uint16_t> ctu_wave;     // per CTU: wave (0 = no intra blocks)
   std::vector<uint16_t> ictu_wave;    // parallel to ictu before sorting
   int ctu_dep_wave;                   // highest wave among the CTUs whose intra blocks the CTU being added reads
@@ -88,8 +94,10 @@ struct PackedPicture {
   const hevcrecon_slice_params *slice_at(uint32_t start) const;
   bool build_ctu_info();
   void build_mc_lists();
-  void split_mc(int x0, int y0, int level);
-  int classify_mc(int x0, int y0, int size, McTile *out) const;
+  void split_mc(int addr, int x0, int y0, int level);
+  int classify_mc(int addr, int x0, int y0, int size, McTile *out) const;
+  bool mc_of_record(const Part4 &p, McTile *t) const;
+  const Part4 &unit(int ux, int uy) const;
 };
 
 #endif

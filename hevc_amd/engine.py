@@ -153,6 +153,31 @@ class Engine:
         self._check(self.lib.hevcrecon_picture_md5_batch(self.ctx, n, (C.c_int * n)(*pic_ids), out.ctypes.data), "hevcrecon_picture_md5_batch")
         return [[out[48 * i + 16 * c:48 * i + 16 * c + 16].tobytes().hex() for c in range(3)] for i in range(n)]
 
+    def md5_submit(self, pic_ids):
+        """Queue the hash of these pictures beside later reconstruction; returns a ticket for md5_poll / md5_wait."""
+        n = len(pic_ids)
+        t = C.c_int64(-1)
+        self._check(self.lib.hevcrecon_picture_md5_submit(self.ctx, n, (C.c_int * n)(*pic_ids), C.byref(t)), "hevcrecon_picture_md5_submit")
+        return (t.value, n)
+
+    @staticmethod
+    def _digests(out, n):
+        return [[out[48 * i + 16 * c:48 * i + 16 * c + 16].tobytes().hex() for c in range(3)] for i in range(n)]
+
+    def md5_poll(self, ticket):
+        """None while the digests are not back yet, else the digests (the ticket is then spent)."""
+        t, n = ticket
+        out = np.empty(48 * n, np.uint8)
+        done = C.c_int(0)
+        self._check(self.lib.hevcrecon_picture_md5_poll(self.ctx, t, C.byref(done), out.ctypes.data), "hevcrecon_picture_md5_poll")
+        return self._digests(out, n) if done.value else None
+
+    def md5_wait(self, ticket):
+        t, n = ticket
+        out = np.empty(48 * n, np.uint8)
+        self._check(self.lib.hevcrecon_picture_md5_wait(self.ctx, t, out.ctypes.data), "hevcrecon_picture_md5_wait")
+        return self._digests(out, n)
+
     def keep_stages(self, on=True):
         self._check(self.lib.hevcrecon_debug_keep_stages(self.ctx, 1 if on else 0), "hevcrecon_debug_keep_stages")
 

@@ -237,12 +237,14 @@ int hevcrecon_syntax_set_scaling_lists(hevcrecon_syntax *syn, const hevcrecon_sc
  * NULL returns to default prediction.  hevcrecon_syntax_begin resets to default. */
 int hevcrecon_syntax_set_pred_weights(hevcrecon_syntax *syn, const hevcrecon_pred_weights *weights);
 
-/* Optional, after hevcrecon_syntax_begin and before the first hevcrecon_syntax_add_ctu: the picture's slices differ in
- * the parameters of hevcrecon_slice_params, or do not all filter across their boundaries.  `slices` holds one entry per
- * slice (any order; copied); every hevcrecon_ctu_syntax.slice_start value of the picture must be the start_addr of one
- * of them, and all partitions of a CTU must belong to one slice.  With a table, the deblocking parameters and slice
- * chroma QP deltas of hevcrecon_pic_params are not used.  n = 0 returns to one set of parameters per picture;
- * hevcrecon_syntax_begin does the same. */
+/* Optional, any time between hevcrecon_syntax_begin and hevcrecon_syntax_finish (a decoder that adds CTUs while it
+ * parses learns of a picture's slices as they arrive, TLibDecoder/TDecTop.cpp:295-600, and hands the table over when
+ * the picture is complete): the picture's slices differ in the parameters of hevcrecon_slice_params, or do not all
+ * filter across their boundaries.  `slices` holds one entry per slice (any order; copied; a later call replaces the
+ * table).  Checked by hevcrecon_syntax_finish: every hevcrecon_ctu_syntax.slice_start value of the picture must be the
+ * start_addr of one of them, and all partitions of a CTU must belong to one slice.  With a table, the deblocking
+ * parameters and slice chroma QP deltas of hevcrecon_pic_params are not used.  n = 0 returns to one set of parameters
+ * per picture; hevcrecon_syntax_begin does the same. */
 int hevcrecon_syntax_set_slices(hevcrecon_syntax *syn, int n, const hevcrecon_slice_params *slices);
 
 /* Replaces the call m_pcCuDecoder->decompressCU(pcCU) in TDecSlice::decompressSlice
@@ -276,8 +278,10 @@ int hevcrecon_reconstruct(hevcrecon_ctx *ctx, hevcrecon_syntax *syn, int dst_pic
  * stream none of which references another) with one set of kernel launches. */
 int hevcrecon_reconstruct_batch(hevcrecon_ctx *ctx, int n, hevcrecon_syntax *const *syn, const int *dst_pic_ids);
 
-/* No counterpart in the reference.  hevcrecon_reconstruct for callers that cannot allocate: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  Same validation, same kernels, same result, but the
+/* No counterpart in the reference.  hevcrecon_reconstruct for callers that cannot allocate: tight serving loops,
+ * harnesses that forbid hipMalloc, set-up code around a graph capture (the call itself still copies the job descriptor
+ * from pinned memory and may wait for an earlier call's copy, so it is not itself meant to be captured).  Same
+ * validation, same kernels, same result, but the
  * call allocates nothing on the device or the host: the job descriptor, the working picture, the residual planes and the
  * intra kernel's scheduling words lie in a fixed 16 MiB array in device memory that belongs to the library (one copy
  * per GPU, held until the process ends), and per-kernel timers and stage copies are off.
@@ -286,9 +290,11 @@ int hevcrecon_reconstruct_batch(hevcrecon_ctx *ctx, int n, hevcrecon_syntax *con
  *     buffers were allocated;
  *   - one picture per call, at most 1920x1088 luma samples (any bit depth): larger pictures are refused with a
  *     message, use hevcrecon_reconstruct for them;
- *   - every call on a GPU uses that GPU's one array: calls are ordered by the context's stream, but calls from
- *     different contexts on the same GPU must not overlap (they would race); the array keeps the last call's
- *     contents, and the call clears what has to start from zero itself. */
+ *   - every call on a GPU uses that GPU's one array: calls of one context are ordered by its stream, and a call
+ *     from another context of the same process queues a wait for the previous user's last kernel first, so
+ *     contexts that take turns are serialised on the device instead of racing (two processes on one GPU each have
+ *     their own copy of the array).  The array keeps the last call's contents, and the call clears what has to
+ *     start from zero itself. */
 int hevcrecon_reconstruct_noalloc(hevcrecon_ctx *ctx, hevcrecon_syntax *syn, int dst_pic_id);
 
 /* Copies the final picture into TComPicYuv-style planes (Pel = int16; strides in samples)
@@ -313,6 +319,17 @@ int hevcrecon_picture_download_file(hevcrecon_ctx *ctx, int pic_id, int file_bit
  * (n up to 4096; a picture may be named more than once).  Blocks until done. */
 int hevcrecon_picture_md5_batch(hevcrecon_ctx *ctx, int n, const int *pic_ids, uint8_t *digests);
 
+/* The same hash without blocking the caller, for a decoder that checks every picture against its SEI message
+ * (TDecGop::calcAndPrintHashStatus, TLibDecoder/TDecGop.cpp:233-236,255-321) and must not stall on it: the hash kernel
+ * is queued on a stream of the context's own, behind everything queued so far and beside the reconstruction of later
+ * pictures; *ticket names the request.  hevcrecon_picture_md5_poll sets *done and fills digests (n x 3 x 16 bytes, as
+ * above) once the digests are back, hevcrecon_picture_md5_wait blocks until then; either collects a ticket once.  Up
+ * to 64 tickets may be outstanding.  A later call that would overwrite one of the pictures (reconstruction into its
+ * id, hevcrecon_picture_copy, _upload, _release) is ordered behind the hash kernel by the engine. */
+int hevcrecon_picture_md5_submit(hevcrecon_ctx *ctx, int n, const int *pic_ids, int64_t *ticket);
+int hevcrecon_picture_md5_poll(hevcrecon_ctx *ctx, int64_t ticket, int *done, uint8_t *digests);
+int hevcrecon_picture_md5_wait(hevcrecon_ctx *ctx, int64_t ticket, uint8_t *digests);
+
 /* Stage-level parity checks: after hevcrecon_debug_keep_stages(ctx, 1) every reconstruct call also keeps a
  * copy of its first picture before deblocking (stage 0) and after deblocking, before SAO (stage 1). */
 int hevcrecon_debug_keep_stages(hevcrecon_ctx *ctx, int on);
@@ -332,8 +349,9 @@ int hevcrecon_picture_copy(hevcrecon_ctx *ctx, int dst_pic_id, int src_pic_id, i
 /* Frees the device picture (TComPic buffers being destroyed: TLibDecoder/TDecTop.cpp:98-118). */
 int hevcrecon_picture_release(hevcrecon_ctx *ctx, int pic_id);
 
-/* Waits for everything queued on the context.  Also the place (with hevcrecon_picture_download) where a work list
- * that a kernel refused is reported: non-zero, message in hevcrecon_last_error. */
+/* Waits for everything queued on the context.  Also the place (with every call that brings a picture or its digests
+ * back: hevcrecon_picture_download, _download_file, _md5_batch, _md5_poll / _wait) where a work list that a kernel
+ * refused is reported: non-zero, message in hevcrecon_last_error. */
 int hevcrecon_synchronize(hevcrecon_ctx *ctx);
 
 /* ---- measurement ------------------------------------------------------- */

@@ -2,15 +2,21 @@
 //
 // TEST INFRASTRUCTURE.  This file is compiled together with the reference's own
 // sources (from where they lie, never copied) into oracle/_ref/TAppDecoderBridge.
-// It takes over five reference call sites WITHOUT editing reference source: the build
+// It takes over reference call sites WITHOUT editing reference source: the build
 // renames the reference's definitions with -D macros (see oracle/Makefile) and this
 // file supplies the symbols the rest of the decoder links against:
 //
-//   TDecCu::decompressCU            TLibDecoder/TDecSlice.cpp:367   (per-CTU reconstruction)
+//   TDecCu::decompressCU            TLibDecoder/TDecSlice.cpp:367   (per-CTU reconstruction -> the CTU is packed while the picture is parsed)
+//   TDecGop::filterPicture          TLibDecoder/TDecTop.cpp:203     (picture finish: hand-over, reconstruction, hash check)
 //   TComLoopFilter::loopFilterPic   TLibDecoder/TDecGop.cpp:181     (deblocking)
 //   TComSampleAdaptiveOffset::SAOProcess  TLibDecoder/TDecGop.cpp:199 (SAO)
 //   TComSampleAdaptiveOffset::PCMLFDisableProcess  TLibDecoder/TDecGop.cpp:200 (restoring lossless units after SAO)
 //   TComPic::compressMotion         TLibDecoder/TDecGop.cpp:210     (runs beside the GPU; the picture is fetched after it)
+//   calcMD5                         TLibDecoder/TDecGop.cpp:269     (timed; not called at all when the device hashes)
+//   TComPicYuv::copyToPic +         TLibDecoder/TDecTop.cpp:244,353 (concealment of a lost reference, TDecTop::xCreateLostPicture: the copy
+//   TComSlice::checkThatAllRefPicsAreAvailable   the reference makes is repeated device to device in the engine's picture buffer)
+//   TComPicYuv::extendPicBorder     TLibCommon/TComSlice.cpp:374-400 (host border padding: nothing reads it in engine mode)
+//   TDecTop::deletePicBuffer        App/TAppDecoder/TAppDecTop.cpp:203 (end of decoding: outstanding hash checks are collected)
 //
 // Modes (environment variable HEVCRECON_MODE):
 //   unset / "ref"  : behave exactly like the reference.
@@ -19,39 +25,98 @@
 //                    $HEVCRECON_DUMP (golden-vector generator).  HEVCRECON_DUMP_PLANES=1 adds
 //                    the three stage pictures themselves.
 //   "engine"       : the reference parses only; reconstruction, deblocking and SAO run in the
-//                    engine loaded from $HEVCRECON_LIB (libhevcrecon.so) and the final picture
-//                    is copied back into TComPicYuv, so the reference's own MD5 check, output
-//                    writer and DPB logic keep working unchanged.
+//                    engine loaded from $HEVCRECON_LIB (libhevcrecon.so).  Every CTU is handed to the
+//                    engine's packer as soon as it is parsed (hevcrecon_syntax_add_ctu where decompressCU was),
+//                    so packing rides inside the parse and the picture is ready for the GPU when its last CTU is.
+//                    HEVCRECON_HASH unset / "host": the final picture is copied back into TComPicYuv, so the
+//                    reference's own MD5 check, output writer and DPB logic keep working unchanged.
+//                    HEVCRECON_HASH=device (decoding without -o): no picture crosses the host link at all; the
+//                    engine hashes the pictures on the GPU beside the reconstruction of later ones
+//                    (hevcrecon_picture_md5_submit / _poll) and the status lines, printed in the reference's format
+//                    with its (OK) / (***ERROR***) verdicts and exit code, follow a few pictures later.
+//   "pack"         : the reference reconstructs as usual; the CTUs are additionally packed into a host-only
+//                    syntax object exactly as in engine mode (no GPU needed): timing and tests of the host side.
+//   HEVCRECON_TIMING=1 prints one line of JSON to stderr when decoding ends: where the host thread's time went.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <deque>
 #include <map>
+#include <string>
 #include <vector>
 #include <dlfcn.h>
 
 // Declare both the renamed reference definition (xxx_ref) and the symbol this file supplies (xxx)
 // inside the reference's own class declarations.
+#define copyToPic copyToPic_ref(TComPicYuv *pcPicYuvDst); Void copyToPic
+#define extendPicBorder extendPicBorder_ref(); Void extendPicBorder
+#include "TLibCommon/TComPicYuv.h"
+#undef copyToPic
+#undef extendPicBorder
+void calcMD5_ref(TComPicYuv &pic, UChar digest[3][16]);
+#define checkThatAllRefPicsAreAvailable \
+  checkThatAllRefPicsAreAvailable_ref(TComList<TComPic *> &rcListPic, TComReferencePictureSet *pReferencePictureSet, Bool printErrors, Int pocRandomAccess); \
+  Int checkThatAllRefPicsAreAvailable
+#include "TLibCommon/TComSlice.h"
+#undef checkThatAllRefPicsAreAvailable
 #define decompressCU decompressCU_ref(TComDataCU *pcCU); Void decompressCU
 #define loopFilterPic loopFilterPic_ref(TComPic *pcPic); Void loopFilterPic
 #define SAOProcess SAOProcess_ref(SAOParam *pcSaoParam); Void SAOProcess
 #define PCMLFDisableProcess PCMLFDisableProcess_ref(TComPic *pcPic); Void PCMLFDisableProcess
 #define compressMotion compressMotion_ref(); Void compressMotion
+#define filterPicture filterPicture_ref(TComPic *&rpcPic); Void filterPicture
+#define deletePicBuffer deletePicBuffer_ref(); Void deletePicBuffer
 #include "TLibDecoder/TDecCu.h"
 #include "TLibCommon/TComLoopFilter.h"
 #include "TLibCommon/TComSampleAdaptiveOffset.h"
 #include "TLibCommon/TComPic.h"
+#include "TLibDecoder/TDecGop.h"
+#include "TLibDecoder/TDecTop.h"
 #undef decompressCU
 #undef loopFilterPic
 #undef SAOProcess
 #undef PCMLFDisableProcess
 #undef compressMotion
+#undef filterPicture
+#undef deletePicBuffer
 #include "libmd5/MD5.h"
 
 #include "../include/hevcrecon.h"
 
+extern bool g_md5_mismatch;  // App/TAppDecoder/decmain.cpp:46: turns into the decoder's exit code
+
 namespace {
 
-enum Mode { MODE_REF, MODE_DUMP, MODE_ENGINE };
+enum Mode { MODE_REF, MODE_DUMP, MODE_ENGINE, MODE_PACK };
+
+double now() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+double wall_clock() {
+  timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+// Where the host thread's time goes, in seconds (HEVCRECON_TIMING=1): everything between the first and the last
+// picture that is not listed here is the reference's own work (parsing, its bookkeeping, output).
+struct Timing {
+  bool on = false;
+  long pictures = 0, ctus = 0, repacked = 0, hash_batches = 0;
+  double t_process = 0, t_first = 0, t_last = 0, wall_first = 0, wall_last = 0;
+  double engine_init = 0;  // loading the library + hevcrecon_create (GPU initialisation)
+  double pack = 0;         // fill_ctu + hevcrecon_syntax_add_ctu, inside the parse
+  double finish = 0;       // picture parameters + hevcrecon_syntax_finish
+  double submit = 0;       // hevcrecon_reconstruct (queues copies and kernels)
+  double motion = 0;       // TComPic::compressMotion of the reference (runs beside the GPU)
+  double wait = 0;         // waiting for the GPU before the picture is fetched
+  double download = 0;     // device-to-host copy + conversion into TComPicYuv
+  double md5_host = 0;     // the reference's calcMD5 on the host thread
+  double hash_device = 0;  // submitting and polling the device hash
+};
 
 struct EngineApi {
   void *lib;
@@ -67,6 +132,24 @@ struct EngineApi {
   int (*syntax_finish)(hevcrecon_syntax *, const hevcrecon_pic_params *);
   int (*reconstruct)(hevcrecon_ctx *, hevcrecon_syntax *, int);
   int (*picture_download)(hevcrecon_ctx *, int, int16_t *, int16_t *, int16_t *, int, int);
+  int (*picture_copy)(hevcrecon_ctx *, int, int, int);
+  int (*synchronize)(hevcrecon_ctx *);
+  int (*md5_submit)(hevcrecon_ctx *, int, const int *, int64_t *);
+  int (*md5_poll)(hevcrecon_ctx *, int64_t, int *, uint8_t *);
+  int (*md5_wait)(hevcrecon_ctx *, int64_t, uint8_t *);
+  int (*syntax_create_detached)(const hevcrecon_seq_params *, hevcrecon_syntax **);
+  const char *(*syntax_last_error)(const hevcrecon_syntax *);
+  void (*syntax_destroy)(hevcrecon_syntax *);
+};
+
+// A status line whose hash verdict is still to come (HEVCRECON_HASH=device)
+struct PendingLine {
+  std::string text;          // "POC ... [L1 ...] " as the reference prints it
+  bool check;                // an MD5 SEI message came with the picture
+  unsigned char want[3][16]; // its digests
+  int pic_id;
+  int64_t ticket;            // -1: not submitted yet
+  int index;                 // position inside its ticket
 };
 
 struct Bridge {
@@ -77,10 +160,21 @@ struct Bridge {
   std::map<TComPic *, int> pic_ids;
   EngineApi api;
   hevcrecon_ctx *ctx;
-  hevcrecon_syntax *syn;
+  // Packed pictures in flight: a syntax object is rewritten only when the GPU is done with the picture it held, so
+  // the decoder rotates over a few of them and never waits for that.
+  enum { kSyntaxObjects = 4 };
+  hevcrecon_syntax *syns[kSyntaxObjects];
+  int syn_pos;
+  hevcrecon_syntax *syn;  // the one the picture being parsed is packed into
+  bool device_hash;
+  Timing tm;
   unsigned char stage_md5[3][3][16];
   std::vector<uint16_t> stage_planes[3];
-  Bridge() : mode(MODE_REF), dump(NULL), dump_planes(false), header_written(false), ctx(NULL), syn(NULL) {
+  Bridge() : mode(MODE_REF), dump(NULL), dump_planes(false), header_written(false), ctx(NULL), syn_pos(0), syn(NULL), device_hash(false) {
+    memset(syns, 0, sizeof(syns));
+    memset(&api, 0, sizeof(api));
+    tm.on = getenv("HEVCRECON_TIMING") && atoi(getenv("HEVCRECON_TIMING"));
+    tm.t_process = now();
     const char *m = getenv("HEVCRECON_MODE");
     if (m && !strcmp(m, "dump")) {
       mode = MODE_DUMP;
@@ -88,15 +182,43 @@ struct Bridge {
       dump = fopen(path ? path : "hevcrecon.syn", "wb");
       if (!dump) { perror("HEVCRECON_DUMP"); exit(EXIT_FAILURE); }
       dump_planes = getenv("HEVCRECON_DUMP_PLANES") && atoi(getenv("HEVCRECON_DUMP_PLANES"));
-    } else if (m && !strcmp(m, "engine")) {
-      mode = MODE_ENGINE;
+    } else if (m && (!strcmp(m, "engine") || !strcmp(m, "pack"))) {
+      mode = !strcmp(m, "engine") ? MODE_ENGINE : MODE_PACK;
+      const double t0 = now();
       load_engine();
+      tm.engine_init = now() - t0;
+      const char *h = getenv("HEVCRECON_HASH");
+      device_hash = mode == MODE_ENGINE && h && !strcmp(h, "device");
+      if (device_hash && writes_output_file()) {
+        fprintf(stderr, "hm_bridge: HEVCRECON_HASH=device keeps the pictures on the GPU; an output file was asked for, so they are fetched and hashed on the host\n");
+        device_hash = false;
+      }
     }
   }
   ~Bridge() { if (dump) fclose(dump); }
 
+  // Was the decoder started with -o / --ReconFile?  (App/TAppDecoder/TAppDecCfg.cpp:68-82; the option parser is the
+  // application's and out of this file's reach, so the command line is read where the kernel keeps it.)
+  static bool writes_output_file() {
+    FILE *f = fopen("/proc/self/cmdline", "rb");
+    if (!f) return true;
+    std::string all;
+    char buf[4096];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) all.append(buf, n);
+    fclose(f);
+    bool first = true, found = false;
+    for (size_t i = 0; i < all.size(); i += strlen(all.c_str() + i) + 1) {
+      const char *a = all.c_str() + i;
+      if (!first && (!strcmp(a, "-o") || !strncmp(a, "--ReconFile", 11))) found = true;
+      first = false;
+    }
+    return found;
+  }
+
   void fail(const char *what) {
-    fprintf(stderr, "hm_bridge: %s: %s\n", what, (ctx && api.last_error) ? api.last_error(ctx) : "");
+    const char *why = (ctx && api.last_error) ? api.last_error(ctx) : (syn && api.syntax_last_error) ? api.syntax_last_error(syn) : "";
+    fprintf(stderr, "hm_bridge: %s: %s\n", what, why);
     exit(EXIT_FAILURE);
   }
   template <class F> void sym(F &f, const char *name) {
@@ -119,7 +241,18 @@ struct Bridge {
     sym(api.syntax_finish, "hevcrecon_syntax_finish");
     sym(api.reconstruct, "hevcrecon_reconstruct");
     sym(api.picture_download, "hevcrecon_picture_download");
-    if (api.create(&ctx, 0)) fail("hevcrecon_create");
+    sym(api.picture_copy, "hevcrecon_picture_copy");
+    sym(api.synchronize, "hevcrecon_synchronize");
+    sym(api.md5_submit, "hevcrecon_picture_md5_submit");
+    sym(api.md5_poll, "hevcrecon_picture_md5_poll");
+    sym(api.md5_wait, "hevcrecon_picture_md5_wait");
+    sym(api.syntax_create_detached, "hevcrecon_syntax_create_detached");
+    sym(api.syntax_last_error, "hevcrecon_syntax_last_error");
+    sym(api.syntax_destroy, "hevcrecon_syntax_destroy");
+    if (mode == MODE_ENGINE) {
+      const char *dev = getenv("HEVCRECON_DEVICE");
+      if (api.create(&ctx, dev ? atoi(dev) : 0)) fail("hevcrecon_create");
+    }
   }
 
   int pic_id(TComPic *p) {
@@ -454,34 +587,106 @@ struct Bridge {
     fflush(dump);
   }
 
-  void engine_picture(TComPic *pic) {
+  // ---- engine / pack mode: the picture is packed while it is parsed ---------------------------------------
+  TComPic *cur = NULL;   // picture whose CTUs are being added
+  int cur_added = 0;     // CTUs added so far (they arrive in coding order)
+  bool cur_ok = false;   // false: something arrived out of order, the picture is packed again from its arrays at the end
+  hevcrecon_pic_params cur_pp;
+
+  void begin_picture(TComPic *pic) {
     hevcrecon_seq_params sp;
     fill_seq(pic, sp);
-    if (api.sequence_init(ctx, &sp)) fail("hevcrecon_sequence_init");
-    if (!syn && api.syntax_create(ctx, &syn)) fail("hevcrecon_syntax_create");
+    if (mode == MODE_ENGINE) {
+      if (api.sequence_init(ctx, &sp)) fail("hevcrecon_sequence_init");
+      syn_pos = (syn_pos + 1) % kSyntaxObjects;
+      if (!syns[syn_pos] && api.syntax_create(ctx, &syns[syn_pos])) fail("hevcrecon_syntax_create");
+    } else {
+      if (syns[0] && memcmp(&sp, &pack_sp, sizeof(sp))) {
+        api.syntax_destroy(syns[0]);
+        syns[0] = NULL;
+      }
+      pack_sp = sp;
+      if (!syns[0] && api.syntax_create_detached(&sp, &syns[0])) fail("hevcrecon_syntax_create_detached");
+      syn_pos = 0;
+    }
+    syn = syns[syn_pos];
+    if (api.syntax_begin(syn)) fail("hevcrecon_syntax_begin");
+    // what fill_ctu needs of the picture parameters while the picture is still being parsed: the SAO enables (those of
+    // the first slice, which has arrived by now); everything else is filled in when the picture is complete
+    memset(&cur_pp, 0, sizeof(cur_pp));
+    const bool sao = pic->getSlice(0)->getSPS()->getUseSAO();
+    cur_pp.sao_luma = sao && pic->getSlice(0)->getSaoEnabledFlag();
+    cur_pp.sao_chroma = sao && pic->getSlice(0)->getSaoEnabledFlagChroma();
+    cur = pic;
+    cur_added = 0;
+    cur_ok = true;
+    if (tm.pictures == 0) {
+      tm.t_first = now();
+      tm.wall_first = wall_clock();
+    }
+  }
+  hevcrecon_seq_params pack_sp;
+
+  void add_one_ctu(TComPic *pic, int addr) {
+    hevcrecon_ctu_syntax cs;
+    int8_t refbuf[2 * HEVCRECON_PARTS_PER_CTU];
+    uint32_t slicebuf[HEVCRECON_PARTS_PER_CTU];
+    fill_ctu(pic, addr, cur_pp, cs, refbuf, slicebuf);
+    if (api.syntax_add_ctu(syn, addr, &cs)) fail("hevcrecon_syntax_add_ctu");
+  }
+
+  // Where the reference reconstructed the CTU it had just parsed (TLibDecoder/TDecSlice.cpp:366-367)
+  void ctu_parsed(TComDataCU *cu) {
+    const double t0 = now();
+    TComPic *pic = cu->getPic();
+    if (pic != cur) begin_picture(pic);
+    if (cur_ok) {
+      const int addr = (int)cu->getAddr();
+      if ((int)pic->getPicSym()->getInverseCUOrderMap(addr) != cur_added) {
+        cur_ok = false;  // a CTU twice (a slice that ends inside it) or one missing: pack from the arrays at the end
+      } else {
+        add_one_ctu(pic, addr);
+        cur_added++;
+        tm.ctus++;
+      }
+    }
+    tm.pack += now() - t0;
+  }
+
+  // The picture is complete (TDecGop::filterPicture): the rest of the hand-over, then the GPU takes over.
+  void finish_picture(TComPic *pic) {
+    double t0 = now();
+    const int nctu = pic->getNumCUsInFrame();
+    if (cur != pic || !cur_ok || cur_added != nctu) {
+      begin_picture(pic);
+      for (int i = 0; i < nctu; i++) add_one_ctu(pic, (int)pic->getPicSym()->getCUOrderMap(i));  // coding order (tile scan)
+      tm.repacked++;
+      tm.pack += now() - t0;
+      t0 = now();
+    }
     hevcrecon_pic_params pp;
     fill_pic(pic, pp);
     check_slices(pic);
-    if (api.syntax_begin(syn)) fail("hevcrecon_syntax_begin");
     hevcrecon_scaling_lists sl;
     if (fill_scaling(pic, sl) && api.syntax_set_scaling_lists(syn, &sl)) fail("hevcrecon_syntax_set_scaling_lists");
     hevcrecon_pred_weights pw;
     if (fill_weights(pic, pw) && api.syntax_set_pred_weights(syn, &pw)) fail("hevcrecon_syntax_set_pred_weights");
     std::vector<hevcrecon_slice_params> slices;
     if (fill_slices(pic, pp, slices) && api.syntax_set_slices(syn, (int)slices.size(), &slices[0])) fail("hevcrecon_syntax_set_slices");
-    int nctu = pic->getNumCUsInFrame();
-    for (int i = 0; i < nctu; i++) {
-      const int a = (int)pic->getPicSym()->getCUOrderMap(i);  // coding order (tile scan)
-      hevcrecon_ctu_syntax cs;
-      int8_t refbuf[2 * HEVCRECON_PARTS_PER_CTU];
-      uint32_t slicebuf[HEVCRECON_PARTS_PER_CTU];
-      fill_ctu(pic, a, pp, cs, refbuf, slicebuf);
-      if (api.syntax_add_ctu(syn, a, &cs)) fail("hevcrecon_syntax_add_ctu");
-    }
     if (api.syntax_finish(syn, &pp)) fail("hevcrecon_syntax_finish");
-    int id = pic_id(pic);
-    if (api.reconstruct(ctx, syn, id)) fail("hevcrecon_reconstruct");  // queued: the GPU works from here on
-    pending = pic;
+    cur = NULL;
+    tm.finish += now() - t0;
+    if (mode == MODE_ENGINE) {
+      t0 = now();
+      const int id = pic_id(pic);
+      submit_hashes_reading(id);  // a picture still waiting for its hash must not be overwritten before the hash is queued
+      if (api.reconstruct(ctx, syn, id)) fail("hevcrecon_reconstruct");  // queued: the GPU works from here on
+      pending = pic;
+      tm.submit += now() - t0;
+    }
+    tm.pictures++;
+    tm.t_last = now();
+    tm.wall_last = wall_clock();
   }
 
   // The picture is fetched only when the decoder is about to need it: after TComPic::compressMotion
@@ -489,13 +694,122 @@ struct Bridge {
   // motion field runs beside the GPU's reconstruction instead of after it.  The packer copied the motion vectors
   // when the CTUs were added, before compressMotion changes them.
   TComPic *pending = NULL;
+  TComPicYuv *lost_src_yuv = NULL, *lost_dst_yuv = NULL;  // the copy TDecTop::xCreateLostPicture has just made
   void engine_fetch(TComPic *pic) {
     if (pending != pic) return;
     pending = NULL;
+    if (device_hash) return;  // the picture stays on the GPU
+    double t0 = now();
+    if (api.synchronize(ctx)) fail("hevcrecon_synchronize");
+    tm.wait += now() - t0;
+    t0 = now();
     TComPicYuv *yuv = pic->getPicYuvRec();
     if (api.picture_download(ctx, pic_id(pic), yuv->getLumaAddr(), yuv->getCbAddr(), yuv->getCrAddr(), yuv->getStride(),
                              yuv->getCStride()))
       fail("hevcrecon_picture_download");
+    tm.download += now() - t0;
+    tm.t_last = now();
+    tm.wall_last = wall_clock();
+  }
+
+  // ---- HEVCRECON_HASH=device: status lines wait for their digests -----------------------------------------------
+  std::deque<PendingLine> lines;     // in decoding order
+  std::deque<int64_t> tickets;       // hash requests in flight, oldest first
+  std::deque<int> ticket_sizes;
+
+  void submit_hashes() {
+    std::vector<int> ids;
+    for (size_t i = 0; i < lines.size(); i++)
+      if (lines[i].check && lines[i].ticket < 0 && lines[i].index < 0) ids.push_back(lines[i].pic_id);
+    if (ids.empty()) return;
+    int64_t t = -1;
+    if (api.md5_submit(ctx, (int)ids.size(), &ids[0], &t)) fail("hevcrecon_picture_md5_submit");
+    int k = 0;
+    for (size_t i = 0; i < lines.size(); i++)
+      if (lines[i].check && lines[i].ticket < 0 && lines[i].index < 0) {
+        lines[i].ticket = t;
+        lines[i].index = k++;
+      }
+    tickets.push_back(t);
+    ticket_sizes.push_back(k);
+    tm.hash_batches++;
+  }
+  void submit_hashes_reading(int id) {
+    for (size_t i = 0; i < lines.size(); i++)
+      if (lines[i].check && lines[i].ticket < 0 && lines[i].index < 0 && lines[i].pic_id == id) {
+        submit_hashes();
+        return;
+      }
+  }
+  // The verdict of TDecGop.cpp:294-320, printed behind the line it belongs to
+  void print_line(const PendingLine &l, unsigned char got[3][16]) {
+    fputs(l.text.c_str(), stdout);
+    if (!l.check) {
+      printf("[:,(unk)] ");
+      return;
+    }
+    const bool ok = !memcmp(got, l.want, 48);
+    printf("[MD5:%s,%s] ", digestToString(got, 16), ok ? "(OK)" : "(***ERROR***)");
+    if (!ok) {
+      g_md5_mismatch = true;
+      unsigned char rx[3][16];
+      memcpy(rx, l.want, 48);
+      printf("[rxMD5:%s] ", digestToString(rx, 16));
+    }
+  }
+  // Collects what has come back (all of it with `block`), prints the lines that are complete, in order, and keeps one
+  // hash request in flight: the batch size follows the decoder's speed by itself.
+  void pump_hashes(bool block) {
+    const double t0 = now();
+    std::vector<uint8_t> dig;
+    while (!tickets.empty()) {
+      const int n = ticket_sizes.front();
+      dig.resize((size_t)48 * n);
+      int done = 0;
+      if (block) {
+        if (api.md5_wait(ctx, tickets.front(), &dig[0])) fail("hevcrecon_picture_md5_wait");
+        done = 1;
+      } else if (api.md5_poll(ctx, tickets.front(), &done, &dig[0])) {
+        fail("hevcrecon_picture_md5_poll");
+      }
+      if (!done) break;
+      while (!lines.empty() && (!lines.front().check || lines.front().ticket == tickets.front())) {
+        unsigned char got[3][16];
+        if (lines.front().check) memcpy(got, &dig[(size_t)48 * lines.front().index], 48);
+        print_line(lines.front(), got);
+        lines.pop_front();
+      }
+      tickets.pop_front();
+      ticket_sizes.pop_front();
+    }
+    if (tickets.empty()) {
+      while (!lines.empty() && !lines.front().check) {  // lines without a hash to wait for
+        unsigned char none[3][16];
+        print_line(lines.front(), none);
+        lines.pop_front();
+      }
+      submit_hashes();
+      if (block && !tickets.empty()) {
+        tm.hash_device += now() - t0;
+        pump_hashes(true);
+        return;
+      }
+    }
+    tm.hash_device += now() - t0;
+  }
+
+  void report() {
+    if (!tm.on || !tm.pictures) return;
+    const double span = tm.t_last - tm.t_first;
+    const double ours = tm.pack + tm.finish + tm.submit + tm.motion + tm.wait + tm.download + tm.md5_host + tm.hash_device;
+    fprintf(stderr,
+            "hm_bridge timing: {\"mode\": \"%s\", \"hash\": \"%s\", \"pictures\": %ld, \"ctus\": %ld, \"repacked\": %ld, \"hash_batches\": %ld, "
+            "\"startup_s\": %.6f, \"engine_init_s\": %.6f, \"first_to_last_s\": %.6f, \"wall_first\": %.6f, \"wall_last\": %.6f, "
+            "\"pack_s\": %.6f, \"finish_s\": %.6f, \"submit_s\": %.6f, \"motion_s\": %.6f, \"wait_s\": %.6f, \"download_s\": %.6f, "
+            "\"md5_host_s\": %.6f, \"hash_device_s\": %.6f, \"parse_and_rest_s\": %.6f}\n",
+            mode == MODE_ENGINE ? "engine" : "pack", device_hash ? "device" : "host", tm.pictures, tm.ctus, tm.repacked, tm.hash_batches,
+            tm.t_first - tm.t_process, tm.engine_init, span, tm.wall_first, tm.wall_last, tm.pack, tm.finish, tm.submit, tm.motion, tm.wait,
+            tm.download, tm.md5_host, tm.hash_device, span - ours);
   }
 };
 
@@ -507,16 +821,22 @@ Bridge &bridge() {
 }  // namespace
 
 Void TDecCu::decompressCU(TComDataCU *pcCU) {
-  if (bridge().mode == MODE_ENGINE) return;  // reconstruction is deferred to the engine
+  Bridge &b = bridge();
+  if (b.mode == MODE_ENGINE) {  // reconstruction is deferred to the engine; the CTU's syntax is handed over now
+    b.ctu_parsed(pcCU);
+    return;
+  }
   decompressCU_ref(pcCU);
+  if (b.mode == MODE_PACK) b.ctu_parsed(pcCU);
 }
 
 Void TComLoopFilter::loopFilterPic(TComPic *pcPic) {
   Bridge &b = bridge();
   if (b.mode == MODE_ENGINE) {
-    b.engine_picture(pcPic);
+    b.finish_picture(pcPic);
     return;
   }
+  if (b.mode == MODE_PACK) b.finish_picture(pcPic);
   if (b.mode == MODE_DUMP) b.capture_stage(pcPic, 0);
   loopFilterPic_ref(pcPic);
   if (b.mode == MODE_DUMP) b.capture_stage(pcPic, 1);
@@ -540,6 +860,115 @@ Void TComPic::compressMotion() {
     b.capture_stage(this, 2);
     b.write_picture(this);  // before the motion field is sub-sampled
   }
+  const double t0 = now();
   compressMotion_ref();
+  b.tm.motion += now() - t0;
   if (b.mode == MODE_ENGINE) b.engine_fetch(this);
+}
+
+void calcMD5(TComPicYuv &pic, UChar digest[3][16]) {
+  const double t0 = now();
+  calcMD5_ref(pic, digest);
+  bridge().tm.md5_host += now() - t0;
+}
+
+// Host-side border padding of reference pictures (TLibCommon/TComSlice.cpp:374-400 calls it for every reference of every
+// slice): only the reference's own motion compensation reads the border, and in engine mode that never runs.
+Void TComPicYuv::extendPicBorder() {
+  if (bridge().mode == MODE_ENGINE) return;
+  extendPicBorder_ref();
+}
+
+// TDecTop::xCreateLostPicture (TLibDecoder/TDecTop.cpp:214-261) conceals a lost reference with a copy of the nearest
+// picture (:244).  The copy is noted here (the reference chooses source and destination) and repeated in the engine's
+// picture buffer, device to device (hevcrecon_picture_copy), as soon as the decoder's picture list comes by (below).
+Void TComPicYuv::copyToPic(TComPicYuv *pcPicYuvDst) {
+  Bridge &b = bridge();
+  if (b.mode == MODE_ENGINE) {
+    b.lost_src_yuv = this;
+    b.lost_dst_yuv = pcPicYuvDst;
+    if (b.device_hash) return;  // no host copy of any picture exists
+  }
+  copyToPic_ref(pcPicYuvDst);
+}
+
+// Called in a loop by TDecTop::xDecodeSlice until no reference is missing any more (TLibDecoder/TDecTop.cpp:351-356),
+// with the decoder's picture list: the call after a TDecTop::xCreateLostPicture finds the two pictures of the copy
+// noted above in that list and has the engine make the same copy.
+Int TComSlice::checkThatAllRefPicsAreAvailable(TComList<TComPic *> &rcListPic, TComReferencePictureSet *pReferencePictureSet, Bool printErrors,
+                                               Int pocRandomAccess) {
+  Bridge &b = bridge();
+  if (b.mode == MODE_ENGINE && b.lost_dst_yuv) {
+    TComPic *src = NULL, *dst = NULL;
+    for (TComList<TComPic *>::iterator it = rcListPic.begin(); it != rcListPic.end(); ++it) {
+      if ((*it)->getPicYuvRec() == b.lost_src_yuv) src = *it;
+      if ((*it)->getPicYuvRec() == b.lost_dst_yuv) dst = *it;
+    }
+    b.lost_src_yuv = b.lost_dst_yuv = NULL;
+    if (!src || !dst || b.pic_ids.find(src) == b.pic_ids.end()) {
+      fprintf(stderr, "hm_bridge: concealment from a picture the engine never reconstructed\n");
+      exit(EXIT_FAILURE);
+    }
+    b.submit_hashes_reading(b.pic_id(dst));
+    if (b.api.picture_copy(b.ctx, b.pic_id(dst), b.pic_id(src), dst->getSlice(0)->getPOC())) b.fail("hevcrecon_picture_copy");
+  }
+  return checkThatAllRefPicsAreAvailable_ref(rcListPic, pReferencePictureSet, printErrors, pocRandomAccess);
+}
+
+Void TDecGop::filterPicture(TComPic *&rpcPic) {
+  Bridge &b = bridge();
+  const SEImessages *seis = rpcPic->getSEIs();
+  const bool md5_sei = seis && seis->picture_digest && seis->picture_digest->method == SEIDecodedPictureHash::MD5;
+  if (!(b.mode == MODE_ENGINE && b.device_hash && (md5_sei || !(seis && seis->picture_digest) || !m_decodedPictureHashSEIEnabled))) {
+    if (b.mode == MODE_ENGINE && b.device_hash) b.pump_hashes(true);  // keep the lines in order around this picture
+    filterPicture_ref(rpcPic);
+    return;
+  }
+  // The reference's picture finish (TLibDecoder/TDecGop.cpp:171-242) with the in-loop filters on the GPU and the hash
+  // check deferred: hand-over and reconstruction are queued, the motion field is sub-sampled beside them, the status
+  // line is kept until the digests are back.
+  long before = clock();
+  b.finish_picture(rpcPic);
+  rpcPic->compressMotion();
+  TComSlice *sl = rpcPic->getSlice(0);
+  char c = sl->isIntra() ? 'I' : sl->isInterP() ? 'P' : 'B';
+  if (!sl->isReferenced()) c += 32;
+  char buf[256];
+  PendingLine line;
+  m_dDecTime += (double)(clock() - before) / CLOCKS_PER_SEC;
+  snprintf(buf, sizeof(buf), "\nPOC %4d TId: %1d ( %c-SLICE, QP%3d ) [DT %6.3f] ", sl->getPOC(), sl->getTLayer(), c, sl->getSliceQp(), m_dDecTime);
+  line.text = buf;
+  m_dDecTime = 0;
+  for (int l = 0; l < 2; l++) {
+    snprintf(buf, sizeof(buf), "[L%d ", l);
+    line.text += buf;
+    for (int r = 0; r < sl->getNumRefIdx(RefPicList(l)); r++) {
+      snprintf(buf, sizeof(buf), "%d ", sl->getRefPOC(RefPicList(l), r));
+      line.text += buf;
+    }
+    line.text += "] ";
+  }
+  line.check = m_decodedPictureHashSEIEnabled && md5_sei;
+  line.pic_id = b.pic_id(rpcPic);
+  line.ticket = -1;
+  line.index = -1;
+  memset(line.want, 0, sizeof(line.want));
+  if (line.check) memcpy(line.want, seis->picture_digest->digest, 48);
+  if (!m_decodedPictureHashSEIEnabled) {  // the reference prints no hash field at all then
+    fputs(line.text.c_str(), stdout);
+  } else {
+    b.lines.push_back(line);
+    b.pump_hashes(false);
+  }
+  rpcPic->setOutputMark(true);
+  rpcPic->setReconMark(true);
+  m_sliceStartCUAddress.clear();
+  m_LFCrossSliceBoundaryFlag.clear();
+}
+
+Void TDecTop::deletePicBuffer() {
+  Bridge &b = bridge();
+  if (b.mode == MODE_ENGINE && b.device_hash) b.pump_hashes(true);
+  b.report();
+  deletePicBuffer_ref();
 }

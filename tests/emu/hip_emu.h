@@ -49,7 +49,7 @@ inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return
 typedef int hipError_t;
 typedef void *hipStream_t;
 typedef struct EmuEvent { double t; } *hipEvent_t;
-enum { hipSuccess = 0, hipErrorNoDevice = 100 };
+enum { hipSuccess = 0, hipErrorNoDevice = 100, hipErrorNotReady = 600 };
 enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 };
 
 extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
@@ -153,6 +153,8 @@ inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp,
 template <typename T> inline hipError_t hipGetSymbolAddress(void **p, T &symbol) { *p = (void *)&symbol; return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+enum { hipStreamNonBlocking = 1 };
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
@@ -166,6 +168,7 @@ inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now_ms(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 
 #endif

@@ -154,8 +154,9 @@ def test_out_of_range_syntax_is_refused(field, value, what):
 
 
 def test_slice_table_is_checked():
-    """hevcrecon_syntax_set_slices: only before the first CTU, values in range, every CTU's slice in the table, and
-    slices that end at CTU boundaries."""
+    """hevcrecon_syntax_set_slices: any time between begin and finish (a decoder learns of a picture's slices as they
+    arrive), values in range; when the picture closes every CTU's slice must be in the table and the slices must end
+    at CTU boundaries."""
     seq = load_golden("slices_nolf_416x240", 1)
     pic = seq.pictures[0]
     lib = abi.load_library()
@@ -169,15 +170,23 @@ def test_slice_table_is_checked():
     assert "out of range" in lib.hevcrecon_syntax_last_error(syn.h).decode()
     table[1].tc_offset_div2 = 0
     assert lib.hevcrecon_syntax_set_slices(syn.h, n, C.addressof(table)) == 0  # a refused table does not spoil the picture
-    assert lib.hevcrecon_syntax_add_ctu(syn.h, 0, C.byref(ctus[0])) == 0
-    assert lib.hevcrecon_syntax_set_slices(syn.h, n, C.addressof(table)) != 0  # too late
-    # a table without the second slice: its first CTU (address 5) is refused
+    # the table may come after the CTUs: packed either way, the picture is the same
+    early = engine.detached_syntax(seq.seq_params).pack(pic)
+    assert lib.hevcrecon_syntax_begin(syn.h) == 0
+    for a in range(pic.nctu):
+        assert lib.hevcrecon_syntax_add_ctu(syn.h, a, C.byref(ctus[a])) == 0
+    assert lib.hevcrecon_syntax_set_slices(syn.h, n, C.addressof(table)) == 0
+    assert lib.hevcrecon_syntax_finish(syn.h, C.byref(pic.pic_params)) == 0
+    assert syn.stats() == early.stats()
+    assert lib.hevcrecon_syntax_set_slices(syn.h, n, C.addressof(table)) != 0  # too late: the picture is closed
+    early.close()
+    # a table without the second slice: refused when the picture closes
     assert lib.hevcrecon_syntax_begin(syn.h) == 0
     short = (abi.SliceParams * 1).from_buffer_copy(bytes(table[0]))
     assert lib.hevcrecon_syntax_set_slices(syn.h, 1, C.addressof(short)) == 0
-    for a in range(5):
+    for a in range(pic.nctu):
         assert lib.hevcrecon_syntax_add_ctu(syn.h, a, C.byref(ctus[a])) == 0
-    assert lib.hevcrecon_syntax_add_ctu(syn.h, 5, C.byref(ctus[5])) != 0
+    assert lib.hevcrecon_syntax_finish(syn.h, C.byref(pic.pic_params)) != 0
     assert "slice table" in lib.hevcrecon_syntax_last_error(syn.h).decode()
     # a slice that starts inside a CTU
     assert lib.hevcrecon_syntax_begin(syn.h) == 0
@@ -186,7 +195,10 @@ def test_slice_table_is_checked():
     starts[128:] = table[1].start_addr
     broken = abi.CtuSyntax.from_buffer_copy(bytes(ctus[0]))
     broken.slice_start = starts.ctypes.data
-    assert lib.hevcrecon_syntax_add_ctu(syn.h, 0, C.byref(broken)) != 0
+    assert lib.hevcrecon_syntax_add_ctu(syn.h, 0, C.byref(broken)) == 0
+    for a in range(1, pic.nctu):
+        assert lib.hevcrecon_syntax_add_ctu(syn.h, a, C.byref(ctus[a])) == 0
+    assert lib.hevcrecon_syntax_finish(syn.h, C.byref(pic.pic_params)) != 0
     assert "CTU boundaries" in lib.hevcrecon_syntax_last_error(syn.h).decode()
     # n = 0 returns to one set of parameters
     assert lib.hevcrecon_syntax_begin(syn.h) == 0
