@@ -122,23 +122,88 @@ def cpu_baseline(seconds_target=10.0):
             "sample": "first %d pictures of the 1080p RA stream through oracle/recon_ref.c (reconstruction only), %.1f s" % (len(seq.pictures), dt)}
 
 
-def end_to_end(device):
-    """The reference decoder's own CLI on the 1080p RA bitstream with the engine behind it (oracle/_ref/TAppDecoderBridge,
-    HEVCRECON_MODE=engine: the reference parses, the GPU reconstructs, the reference checks every MD5) beside the
-    unmodified reference decoder, same host, wall clock of the whole process, best of two."""
-    if not (os.path.exists(BRIDGE_DECODER) and os.path.exists(REF_DECODER) and os.path.exists(RA_BITSTREAM)):
-        return None
+def _bridge_env(device, hash_mode):
     from hevc_amd import abi
 
-    env = dict(os.environ, HEVCRECON_MODE="engine", HEVCRECON_LIB=abi.LIB_PATH)
+    return dict(os.environ, HEVCRECON_MODE="engine", HEVCRECON_LIB=abi.LIB_PATH, HEVCRECON_DEVICE=str(device), HEVCRECON_HASH=hash_mode,
+                HEVCRECON_TIMING="1")
+
+
+def _bridge_timing(stderr_bytes):
+    import re
+
+    m = re.search(r"hm_bridge timing: (\{.*\})", stderr_bytes.decode("latin1"))
+    return json.loads(m.group(1)) if m else None
+
+
+def _per_picture_ms(ts):
+    """Average host time per picture (ms) over the timing records of one or more decoder processes."""
+    n = sum(t["pictures"] for t in ts)
+    keys = ["parse_and_rest_s", "pack_s", "finish_s", "submit_s", "motion_s", "wait_s", "download_s", "md5_host_s", "hash_device_s"]
+    return {k[:-2]: round(sum(t[k] for t in ts) / n * 1e3, 3) for k in keys}
+
+
+def end_to_end(device, n_proc, loops=8):
+    """Decoded frames/s through the reference decoder's own CLI with the engine behind it (oracle/_ref/TAppDecoderBridge,
+    HEVCRECON_MODE=engine: the reference parses, every CTU is packed where the reference would have reconstructed it,
+    the GPU reconstructs).  Must run before this process has touched the GPU (the decoders are GPU processes of their
+    own).
+      concurrent: n_proc decoder processes share the GPU, one stream per host core like the CPU baseline, each
+        decoding the 60-frame 1080p RA stream `loops` times over (the bitstream concatenated with itself: every copy
+        starts with parameter sets and an IDR picture), pictures hashed on the GPU (HEVCRECON_HASH=device) and checked
+        against the SEI digests by the decoder itself; timed from the first process's first picture to the last
+        process's last one (wall clocks of the processes), process start and GPU initialisation reported apart;
+      one_process: the same stream once, (a) with the device hash, (b) with every picture fetched and hashed by the
+        reference on the host thread (what writing an output file costs), (c) the unmodified reference decoder;
+      per_picture_ms: where a decoder's host thread spends a picture's time (clock_gettime around each stage
+        inside the bridge)."""
+    if not (os.path.exists(BRIDGE_DECODER) and os.path.exists(REF_DECODER) and os.path.exists(RA_BITSTREAM)):
+        return None
+    import tempfile
+
+    out = {"frames_per_stream": 60}
     try:
-        t_eng = min(_decode_once(BRIDGE_DECODER, env) for _ in range(2))
-        t_ref = min(_decode_once(REF_DECODER) for _ in range(2))
+        with tempfile.TemporaryDirectory() as tmp:
+            looped = os.path.join(tmp, "looped.bin")
+            one = open(RA_BITSTREAM, "rb").read()
+            with open(looped, "wb") as f:
+                for _ in range(loops):
+                    f.write(one)
+            env = _bridge_env(device, "device")
+            t0 = time.time()
+            procs = [subprocess.Popen([BRIDGE_DECODER, "-b", looped], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for _ in range(n_proc)]
+            res = [p.communicate() for p in procs]
+            wall = time.time() - t0
+            ts = []
+            for p, (so, se) in zip(procs, res):
+                t = _bridge_timing(se)
+                if p.returncode != 0 or so.count(b"(OK)") != 60 * loops or t is None:
+                    raise RuntimeError("a concurrent decoder failed (exit %d, %d of %d pictures OK): %s" % (p.returncode, so.count(b"(OK)"), 60 * loops, se[-300:]))
+                ts.append(t)
+            span = max(t["wall_last"] for t in ts) - min(t["wall_first"] for t in ts)
+            frames = sum(t["pictures"] for t in ts)
+            out["concurrent"] = {
+                "processes": n_proc, "frames": frames, "frames_per_s": round(frames / span, 1), "first_to_last_picture_s": round(span, 3),
+                "frames_per_s_with_start_up": round(frames / wall, 1),
+                "start_up_s": round(sum(t["startup_s"] for t in ts) / n_proc, 3), "gpu_init_s": round(sum(t["engine_init_s"] for t in ts) / n_proc, 3),
+                "hash": "device", "pictures_per_hash_request": round(frames / max(1, sum(t["hash_batches"] for t in ts)), 1),
+                "per_picture_ms": _per_picture_ms(ts)}
+            out["packer_us_per_picture_c"] = round(sum(t["pack_s"] + t["finish_s"] for t in ts) / frames * 1e6, 1)
+            # one process alone
+            single = {}
+            for name, hash_mode in (("device_hash", "device"), ("host_hash", "host")):
+                r = subprocess.run([BRIDGE_DECODER, "-b", RA_BITSTREAM], env=_bridge_env(device, hash_mode), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                t = _bridge_timing(r.stderr)
+                if r.returncode != 0 or r.stdout.count(b"(OK)") != 60 or t is None:
+                    raise RuntimeError("the %s decoder failed: %s" % (name, r.stderr[-300:]))
+                single[name] = {"frames_per_s": round(60 / t["first_to_last_s"], 1), "start_up_s": round(t["startup_s"], 3),
+                                "per_picture_ms": _per_picture_ms([t])}
+            single["engine_behind_reference_cli_frames_per_s_with_start_up"] = round(60 / min(_decode_once(BRIDGE_DECODER, _bridge_env(device, "host")) for _ in range(2)), 2)
+            single["reference_cli_frames_per_s_with_start_up"] = round(60 / min(_decode_once(REF_DECODER) for _ in range(2)), 2)
+            out["one_process"] = single
     except (RuntimeError, subprocess.CalledProcessError, OSError) as e:
-        return {"error": str(e)[:200]}
-    return {"frames": 60, "engine_behind_reference_cli_frames_per_s": round(60 / t_eng, 2), "reference_cli_frames_per_s": round(60 / t_ref, 2),
-            "note": "one stream, one process, wall clock with process start and GPU initialisation; the reference's parser, its "
-                    "per-picture download and its MD5 check run on one host thread and bound the engine-backed decoder"}
+        out["error"] = str(e)[:300]
+    return out
 
 
 def spawn_ranks(n):
@@ -259,6 +324,8 @@ def main():
     ap.add_argument("--upload-ring", action="store_true", help="stage all packed pictures in the context's upload ring (coalesced hand-over copies)")
     ap.add_argument("--check-two-streams-only", action="store_true",
                     help="parity pass without the device hash of every stream (profiling runs: keeps k_md5 out of the kernel statistics)")
+    ap.add_argument("--e2e-procs", type=int, default=0,
+                    help="decoder processes of the end-to-end measurement (default: the host cores of this job, at most 16)")
     ap.add_argument("--rehearse", action="store_true", help="no GPU work: only the multi-rank plumbing (used by the CPU tests)")
     ap.add_argument("--total-streams", type=int, default=0,
                     help="streams of the whole job, dealt to the GPUs round-robin (stream i -> rank i mod N); overrides --streams: "
@@ -306,6 +373,16 @@ def main():
         args.streams = len(sharding.streams_for_rank(args.total_streams, rank, world))
         if args.streams == 0:
             raise SystemExit("bench: fewer streams than GPUs")
+
+    # end to end through the decoder CLI: N decoder processes of their own on the GPU, measured before this process
+    # opens the device (the machine allows only so many GPU processes at once)
+    e2e = None
+    if not args.no_extras and world == 1 and args.fixture == "randomaccess_main_1920x1080":
+        try:
+            ncores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncores = os.cpu_count() or 1
+        e2e = end_to_end(local_rank, args.e2e_procs or max(1, min(16, ncores)))
 
     golden = os.path.join(ROOT, "tests", "golden")
     names = [args.fixture] + ["%s_s%d" % (args.fixture, k) for k in range(1, 8)]
@@ -556,9 +633,10 @@ def main():
                 side["every_stream_at_its_own_position_over_four_contexts_frames_per_s"] = round(2 * npic * S / (time.perf_counter() - t0), 1)
                 W4.close()
         result["fewer_streams"] = side
-        e2e = end_to_end(local_rank)
         if e2e is not None:
             result["end_to_end"] = e2e
+            if "packer_us_per_picture_c" in e2e:
+                result["packer_us_per_picture_c"] = e2e.pop("packer_us_per_picture_c")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:

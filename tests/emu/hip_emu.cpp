@@ -93,3 +93,8 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body) {
 double emu_now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+long g_emu_allocations = 0;
+// For tests of the entry point that must not allocate: how often the engine has asked the (emulated) runtime for
+// device or pinned memory, an event or a stream.
+extern "C" long hevcrecon_emu_allocations() { return g_emu_allocations; }

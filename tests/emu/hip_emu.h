@@ -139,7 +139,8 @@ inline int max(int a, int b) { return a > b ? a : b; }
 // ---- host runtime stand-ins (single "device" = host memory) ----
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
-inline hipError_t hipMalloc(void **p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : 2; }
+extern long g_emu_allocations;  // device / pinned allocations and event / stream creations so far (tests assert on it)
+inline hipError_t hipMalloc(void **p, size_t n) { g_emu_allocations++; *p = std::malloc(n ? n : 1); return *p ? hipSuccess : 2; }
 inline hipError_t hipFree(void *p) { std::free(p); return hipSuccess; }
 inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
@@ -152,18 +153,18 @@ inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp,
 }
 template <typename T> inline hipError_t hipGetSymbolAddress(void **p, T &symbol) { *p = (void *)&symbol; return hipSuccess; }
 inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
-inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t *s) { g_emu_allocations++; *s = nullptr; return hipSuccess; }
 enum { hipStreamNonBlocking = 1 };
-inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { g_emu_allocations++; *s = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 double emu_now_ms();
-inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new EmuEvent{0}; return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { g_emu_allocations++; *e = new EmuEvent{0}; return hipSuccess; }
 enum { hipEventDisableTiming = 2 };
-inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new EmuEvent{0}; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { g_emu_allocations++; *e = new EmuEvent{0}; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }  // everything runs in order
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now_ms(); return hipSuccess; }

@@ -79,6 +79,19 @@ def test_emulated_device_md5(emu_lib, stream):
     assert eng.md5(ids[-1:]) == [seq.pictures[-1].stage_md5[2]]
     with pytest.raises(engine.EngineError):
         eng.md5([999])
+    # the same through tickets (hevcrecon_picture_md5_submit / _poll / _wait); a ticket is spent when collected
+    t1, t2 = eng.md5_submit(ids), eng.md5_submit(ids[:1])
+    assert eng.md5_wait(t2) == [seq.pictures[0].stage_md5[2]]
+    assert eng.md5_poll(t1) == [p.stage_md5[2] for p in seq.pictures]
+    with pytest.raises(engine.EngineError):
+        eng.md5_poll(t1)
+    # more tickets outstanding than the engine keeps track of are refused, and collecting makes room again
+    held = [eng.md5_submit(ids[:1]) for _ in range(64)]
+    with pytest.raises(engine.EngineError):
+        eng.md5_submit(ids[:1])
+    for t in held:
+        assert eng.md5_wait(t) == [seq.pictures[0].stage_md5[2]]
+    assert eng.md5_wait(eng.md5_submit(ids[:1])) == [seq.pictures[0].stage_md5[2]]
     syn.close()
     eng.close()
 
@@ -257,7 +270,13 @@ def _noalloc_call(lib, eng, syn, dst):
 def _noalloc_matches_regular(lib, first, second):
     """hevcrecon_reconstruct_noalloc against hevcrecon_reconstruct, two calls in a row on the device's one fixed work
     area, the second with a smaller input: (fixture, index of the picture to reconstruct both ways) each; the
-    pictures before it are reconstructed the regular way so that its references are resident."""
+    pictures before it are reconstructed the regular way so that its references are resident.  Then the same
+    picture from a freshly packed syntax object whose first reconstruction is the allocation-free one (its hand-over
+    and the expansion of its motion records run inside that call), and two contexts taking turns on the work area
+    without the host waiting in between."""
+    counter = getattr(lib, "hevcrecon_emu_allocations", None)  # the CPU emulation counts what the engine allocates
+    if counter is not None:
+        counter.restype = __import__("ctypes").c_long
     for name, idx in (first, second):
         seq = load_golden(name, idx + 1)
         eng = engine.Engine(seq.seq_params, lib=lib)
@@ -278,6 +297,33 @@ def _noalloc_matches_regular(lib, first, second):
         for c in range(3):
             assert np.array_equal(got[c], want[c]), (name, pic.poc, c)
         assert eng.md5([dst]) == [pic.stage_md5[2]]
+        # a fresh syntax object: nothing of it is on the device yet when the allocation-free call comes
+        fresh = eng.new_syntax().pack(pic)
+        eng.upload(dst + 1, 0, [np.full_like(p, 5) for p in want])
+        before = counter() if counter else 0
+        assert _noalloc_call(lib, eng, fresh, dst + 1) == 0, lib.hevcrecon_last_error(eng.ctx)
+        if counter:
+            assert counter() == before, "hevcrecon_reconstruct_noalloc allocated something"
+        got = eng.download(dst + 1)
+        for c in range(3):
+            assert np.array_equal(got[c], want[c]), (name, pic.poc, c, "fresh syntax")
+        # two contexts, one work area: calls queued alternately, nobody waits on the host in between
+        eng2 = engine.Engine(seq.seq_params, lib=lib)
+        syn2 = eng2.new_syntax()
+        for p in seq.pictures[:idx + 1]:
+            syn2.pack(p)
+            eng2.reconstruct(syn2, p.pic_id)
+        eng2.upload(dst, 0, [np.full_like(p, 9) for p in want])
+        for rep in range(3):
+            assert _noalloc_call(lib, eng, syn, dst) == 0, lib.hevcrecon_last_error(eng.ctx)
+            assert _noalloc_call(lib, eng2, syn2, dst) == 0, lib.hevcrecon_last_error(eng2.ctx)
+        for e in (eng, eng2):
+            got = e.download(dst)
+            for c in range(3):
+                assert np.array_equal(got[c], want[c]), (name, pic.poc, c, "two contexts")
+        syn2.close()
+        eng2.close()
+        fresh.close()
         syn.close()
         eng.close()
 

@@ -123,6 +123,74 @@ def test_device_md5(stream):
     eng.close()
 
 
+def test_device_md5_without_blocking():
+    """hevcrecon_picture_md5_submit / _poll / _wait: every picture of the 1080p stream is queued for hashing right after
+    its reconstruction was, beside the reconstruction of the following pictures (which overwrite picture ids that
+    earlier requests still read: the engine orders those), tickets collected later, one by polling."""
+    import time
+
+    seq = load_golden("randomaccess_main_1920x1080", 24)
+    eng = engine.Engine(seq.seq_params)
+    syns = [eng.new_syntax() for _ in range(4)]
+    tickets = []
+    for k, pic in enumerate(seq.pictures):
+        syns[k % 4].pack(pic)
+        eng.reconstruct(syns[k % 4], pic.pic_id)
+        tickets.append((eng.md5_submit([pic.pic_id]), pic))
+        pic.drop_ctypes()
+    first, pic0 = tickets[0]
+    got = None
+    for _ in range(2000):
+        got = eng.md5_poll(first)
+        if got is not None:
+            break
+        time.sleep(0.005)
+    assert got == [pic0.stage_md5[2]]
+    with pytest.raises(engine.EngineError):
+        eng.md5_wait(first)  # a ticket is collected once
+    for t, pic in tickets[1:]:
+        assert eng.md5_wait(t) == [pic.stage_md5[2]], pic.poc
+    # a batch in one request, and the blocking call beside it
+    ids = sorted({p.pic_id: p for p in seq.pictures})
+    last = {p.pic_id: p for p in seq.pictures}
+    t = eng.md5_submit(ids)
+    assert eng.md5(ids) == [last[i].stage_md5[2] for i in ids]
+    assert eng.md5_wait(t) == [last[i].stage_md5[2] for i in ids]
+    with pytest.raises(engine.EngineError):
+        eng.md5_submit([999])
+    for y in syns:
+        y.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("bits,npics", [("randomaccess_main_1080", 60), ("randomaccess_he10_1080", 60), ("slices_tiles_nolf_240", 9),
+                                        ("pcmlf_240", 4), ("wpb_240", 9), ("intra_main_240", 9)])
+def test_drop_in_with_the_device_hash(bits, npics):
+    """The decoder CLI with HEVCRECON_HASH=device: CTUs packed while the reference parses, no picture crosses the host
+    link, the engine hashes on the GPU beside the reconstruction of later pictures, and the status lines (the
+    reference's format, its (OK) verdicts, its exit code) carry the digests of the unmodified reference decoder."""
+    from test_bridge_cli import BRIDGE, run_bridge, status_lines, timing_of
+    from hevc_amd import abi
+
+    if not os.path.exists(BRIDGE):
+        pytest.skip("bridge decoder not built (needs the reference tree at build time)")
+    rc, out, err = run_bridge(os.path.join(GOLDEN, bits + ".bin"), abi.LIB_PATH, hash_mode="device")
+    assert rc == 0, (out[-1500:], err[-1500:])
+    assert out.count("(OK)") == npics and "ERROR" not in out
+    assert status_lines(out) == json.load(open(os.path.join(GOLDEN, "hm_md5.json")))[bits]
+    t = timing_of(err)
+    assert t["hash"] == "device" and t["repacked"] == 0 and t["download_s"] == 0 and t["md5_host_s"] == 0 and t["pictures"] == npics
+
+
+def test_lost_reference_is_concealed_on_the_gpu(tmp_path):
+    from test_bridge_cli import BRIDGE, lost_picture_case
+    from hevc_amd import abi
+
+    if not os.path.exists(BRIDGE):
+        pytest.skip("bridge decoder not built (needs the reference tree at build time)")
+    lost_picture_case(abi.LIB_PATH, tmp_path)
+
+
 def test_packed_pictures_can_be_uploaded_again():
     """hevcrecon_syntax_upload: a packed picture copied to the device a second time (runs expanded again, while
     other pictures are being reconstructed) gives the same picture; an unfinished one is refused."""
@@ -264,8 +332,12 @@ def _bench_line(cmd, env=None):
 
 @pytest.mark.gpu
 def test_bench_contract_single_gpu():
-    d = _bench_line(["bench.py", "--steps", "1", "--warmup", "1", "--streams", "2", "--no-cpu-baseline"])
+    d = _bench_line(["bench.py", "--steps", "1", "--warmup", "1", "--streams", "2", "--no-cpu-baseline", "--e2e-procs", "2"])
     assert BENCH_KEYS <= set(d)
+    e2e = d.get("end_to_end")
+    if e2e is not None:  # the decoder binaries travel with the tree when they were built
+        assert "error" not in e2e, e2e
+        assert e2e["concurrent"]["processes"] == 2 and e2e["concurrent"]["frames"] == 2 * 8 * 60 and d["packer_us_per_picture_c"] > 0
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and d["config"]["md5_exact"]
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
