@@ -35,6 +35,15 @@ KERNELS = ["k_inter_tile64", "k_inter_tile32", "k_inter_tile16", "k_inter_blk", 
            "k_deblock_h", "k_sao"]
 
 
+_T0 = time.time()
+
+
+def progress(what):
+    """A line on stderr now and then: a run that stays silent for minutes is taken for hung by the job runner."""
+    sys.stderr.write("[bench %6.1f s] %s\n" % (time.time() - _T0, what))
+    sys.stderr.flush()
+
+
 def clone_for_stream(pic, s):
     p = copy.copy(pic)
     p.pic_params = type(pic.pic_params).from_buffer_copy(pic.pic_params)
@@ -125,8 +134,11 @@ def cpu_baseline(seconds_target=10.0):
 def _bridge_env(device, hash_mode):
     from hevc_amd import abi
 
-    return dict(os.environ, HEVCRECON_MODE="engine", HEVCRECON_LIB=abi.LIB_PATH, HEVCRECON_DEVICE=str(device), HEVCRECON_HASH=hash_mode,
-                HEVCRECON_TIMING="1")
+    env = dict(os.environ, HEVCRECON_MODE="engine", HEVCRECON_LIB=abi.LIB_PATH, HEVCRECON_DEVICE=str(device), HEVCRECON_HASH=hash_mode,
+               HEVCRECON_TIMING="1")
+    if os.environ.get("HEVCRECON_E2E_HWQ"):
+        env["GPU_MAX_HW_QUEUES"] = os.environ["HEVCRECON_E2E_HWQ"]
+    return env
 
 
 def _bridge_timing(stderr_bytes):
@@ -189,6 +201,16 @@ def end_to_end(device, n_proc, loops=8):
                 "hash": "device", "pictures_per_hash_request": round(frames / max(1, sum(t["hash_batches"] for t in ts)), 1),
                 "per_picture_ms": _per_picture_ms(ts)}
             out["packer_us_per_picture_c"] = round(sum(t["pack_s"] + t["finish_s"] for t in ts) / frames * 1e6, 1)
+            # the same with every picture fetched and hashed by the reference on the host thread
+            procs = [subprocess.Popen([BRIDGE_DECODER, "-b", looped], env=_bridge_env(device, "host"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                     for _ in range(n_proc)]
+            res = [p.communicate() for p in procs]
+            ts = [_bridge_timing(se) for _, se in res]
+            if all(p.returncode == 0 for p in procs) and all(t is not None for t in ts) and all(so.count(b"(OK)") == 60 * loops for so, _ in res):
+                span = max(t["wall_last"] for t in ts) - min(t["wall_first"] for t in ts)
+                frames = sum(t["pictures"] for t in ts)
+                out["concurrent_host_hash"] = {"processes": n_proc, "frames": frames, "frames_per_s": round(frames / span, 1),
+                                               "per_picture_ms": _per_picture_ms(ts)}
             # one process alone
             single = {}
             for name, hash_mode in (("device_hash", "device"), ("host_hash", "host")):
@@ -245,8 +267,11 @@ class Workload:
         self.syns = [[None] * S for _ in range(self.npic)]
         self.stats = [[None] * self.npic for _ in range(nseeds)]
         self.pack_s, self.pack_n = 0.0, 0
-        for k, seq in enumerate(seqs):
-            for t, pic in enumerate(seq.pictures):
+        # in the order a host with one decoder per stream finishes them: picture t of every stream, then picture t + 1
+        # (what is finished together is staged side by side in a context's upload ring and travels in one copy)
+        for t in range(self.npic):
+            for k, seq in enumerate(seqs):
+                pic = seq.pictures[t]
                 pic.ctu_structs()
                 for s in range(S):
                     if self.seed_of[s] == k:
@@ -257,6 +282,8 @@ class Workload:
                         if self.stats[k][t] is None:
                             self.stats[k][t] = y.stats()
                 pic.drop_ctypes()
+            if t % 10 == 9:
+                progress("packed %d of %d pictures of %d streams" % (t + 1, self.npic, S))
         self.set_offsets(stagger)
 
     def set_offsets(self, stagger):
@@ -321,6 +348,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the side measurements (hand-over, 1 and 8 streams, staggered, end to end)")
     ap.add_argument("--no-handover", action="store_true", help="skip the passes that time the syntax hand-over")
+    ap.add_argument("--extras", default="e2e,handover,fewer,stagger",
+                    help="which side measurements to run (comma separated): e2e (decoder processes through the CLI), handover, "
+                         "fewer (1 and 8 streams), stagger (every stream at its own position)")
     ap.add_argument("--upload-ring", action="store_true", help="stage all packed pictures in the context's upload ring (coalesced hand-over copies)")
     ap.add_argument("--check-two-streams-only", action="store_true",
                     help="parity pass without the device hash of every stream (profiling runs: keeps k_md5 out of the kernel statistics)")
@@ -331,6 +361,9 @@ def main():
                     help="streams of the whole job, dealt to the GPUs round-robin (stream i -> rank i mod N); overrides --streams: "
                          "64 on 8 GPUs is 8 independent streams per GPU")
     args = ap.parse_args()
+    extras = set() if args.no_extras else set(x for x in args.extras.split(",") if x)
+    if args.no_handover:
+        extras.discard("handover")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
@@ -377,12 +410,14 @@ def main():
     # end to end through the decoder CLI: N decoder processes of their own on the GPU, measured before this process
     # opens the device (the machine allows only so many GPU processes at once)
     e2e = None
-    if not args.no_extras and world == 1 and args.fixture == "randomaccess_main_1920x1080":
+    if "e2e" in extras and world == 1 and args.fixture == "randomaccess_main_1920x1080":
         try:
             ncores = len(os.sched_getaffinity(0))
         except AttributeError:
             ncores = os.cpu_count() or 1
+        progress("end to end: decoder processes sharing the GPU")
         e2e = end_to_end(local_rank, args.e2e_procs or max(1, min(16, ncores)))
+        progress("end to end done")
 
     golden = os.path.join(ROOT, "tests", "golden")
     names = [args.fixture] + ["%s_s%d" % (args.fixture, k) for k in range(1, 8)]
@@ -410,6 +445,7 @@ def main():
         return first_step + n_pass * npic
 
     # ramp-up (streams start one after the other) and warm-up passes, then the timed passes
+    progress("warm-up and timed passes")
     g = 0
     while g < W.max_off:
         W.step(g)
@@ -425,6 +461,7 @@ def main():
     # ---- parity: one more (untimed) pass; after every step the picture every stream has just finished is hashed on
     # the device and compared with the reference decoder's MD5 (the decoder recycles picture ids, so the check cannot
     # wait); the first and last stream are also downloaded and hashed on the host
+    progress("timed passes done: %.1f frames/s; checking every picture" % (npic * S * args.steps / elapsed))
     bd = [sp.bit_depth_luma, sp.bit_depth_chroma, sp.bit_depth_chroma]
     checked = 0
     for gg in range(g, g + npic):
@@ -446,6 +483,7 @@ def main():
 
     # ---- per-kernel time with HIP events on the engine's stream (one extra, untimed pass of context 0 alone: with
     # several contexts the kernels of different contexts overlap, so their times are taken without the others) ----
+    progress("per-kernel times")
     eng = engs[0]
     eng.profile_enable(True)
     for gg in range(g, g + npic):
@@ -517,12 +555,13 @@ def main():
         "packer_us_per_picture": round(W.pack_s / max(W.pack_n, 1) * 1e6, 1),
     }
 
-    if not args.no_extras and world == 1:
+    if extras and world == 1:
         # ---- syntax hand-over (never `value`): the packed pictures cross the host link again ----
         # Two passes in which every picture is marked for upload before its batch is submitted: the engine copies a
         # batch's pictures from their pinned buffers on its copy streams, beside the previous batch's kernels, and
         # expands the run-length coded records.  (Packing itself, host work of the decoder, is not repeated.)
-        if not args.no_handover:
+        progress("side measurements: hand-over")
+        if "handover" in extras:
             up_bytes = sum(W.syns[t][s].stats()[29] for t in range(npic) for s in range(S))
             sync()
             t0 = time.perf_counter()
@@ -535,9 +574,10 @@ def main():
                                   "link_gbps": round(up_bytes / t_both / 1e9, 2)}
         # ---- fewer streams: 1 and 8 streams of context 0 alone (what one decoder process, or 64 streams over 8 GPUs
         # = 8 per GPU, get out of the device), and all streams each at its own position ----
+        progress("side measurements: fewer streams")
         side = {}
         for n_small in (1, 8):
-            if n_small <= len(groups[0]):
+            if n_small <= len(groups[0]) and "fewer" in extras:
                 sub = groups[0][:n_small]
                 preps = [engs[0].prepare_batch([W.syns[t][s] for s in sub], [W.pic_id(s, t) for s in sub]) for t in range(npic)]
                 for p in preps:
@@ -549,7 +589,7 @@ def main():
                         engs[0].reconstruct_prepared(p)
                 engs[0].synchronize()
                 side["streams_%d_frames_per_s" % n_small] = round(2 * npic * n_small / (time.perf_counter() - t0), 1)
-        if C >= 2 and len(groups[0]) >= 4 and len(groups[1]) >= 4:
+        if C >= 2 and len(groups[0]) >= 4 and len(groups[1]) >= 4 and "fewer" in extras:
             # the same 8 streams as two contexts of 4, half a pass apart: one context's launch latency and intra chain
             # run beside the other's kernels
             subs = [groups[0][:4], groups[1][:4]]
@@ -563,7 +603,7 @@ def main():
                     engs[1].reconstruct_prepared(preps[1][(t + npic // 2) % npic])
             sync()
             side["streams_8_over_two_contexts_frames_per_s"] = round(2 * npic * 8 / (time.perf_counter() - t0), 1)
-        if len(groups[0]) >= 2:
+        if len(groups[0]) >= 2 and "fewer" in extras:
             # 8 streams over four fresh contexts of 2 (four is the number of hardware queues a process gets): what 64
             # streams over 8 GPUs can get out of each device
             n_ctx, n_str = 4, 8
@@ -601,7 +641,8 @@ def main():
                         y.close()
             for e in engs4:
                 e.close()
-        if not args.stagger and S >= 2 * C:
+        progress("side measurements: every stream at its own position")
+        if not args.stagger and S >= 2 * C and "stagger" in extras:
             W.set_offsets(True)
             gg = 0
             while gg < W.max_off:
@@ -638,6 +679,7 @@ def main():
             if "packer_us_per_picture_c" in e2e:
                 result["packer_us_per_picture_c"] = e2e.pop("packer_us_per_picture_c")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        progress("CPU baseline")
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(result))

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <deque>
@@ -101,17 +102,20 @@ struct DevPicture {
   void *p[3] = {nullptr, nullptr, nullptr};
   int poc = 0;
   bool valid = false;
-  int64_t md5_ticket = -1;  // last hevcrecon_picture_md5_submit that reads the picture (-1: none)
 };
 
-// One hevcrecon_picture_md5_submit in flight: descriptors and digests on the device, digests in pinned memory, and
-// the event behind the copy that brings them back.
+// One hevcrecon_picture_md5_submit in flight: copies of the pictures to hash (the originals may be overwritten as soon
+// as the call returns: a decoder recycles its picture buffers faster than a hash kernel runs), descriptors and
+// digests on the device, digests and the kernels' error words in pinned memory, and the event behind the copy that
+// brings them back.
 struct Md5Slot {
   int64_t ticket = -1;  // -1: free
   int n = 0;
   void *dev = nullptr;
   uint8_t *host = nullptr;
-  size_t cap = 0;  // pictures the buffers hold
+  void *snap = nullptr;  // n pictures, pic_bytes apart
+  size_t cap = 0;        // pictures the buffers hold
+  size_t snap_pic_bytes = 0;
   hipEvent_t done = nullptr;
 };
 const int kMd5Slots = 64;
@@ -403,16 +407,6 @@ int check_device_errors(hevcrecon_ctx *c) {
   return fail(c, m);
 }
 
-// A picture that a queued hevcrecon_picture_md5_submit still reads must not be overwritten before the hash kernel is
-// done with it: the kernels' stream waits for that ticket's event (nothing is allocated here).
-int wait_for_md5_reader(hevcrecon_ctx *c, DevPicture &p) {
-  if (p.md5_ticket < 0) return 0;
-  Md5Slot &m = c->md5_slots[p.md5_ticket % kMd5Slots];
-  if (m.ticket == p.md5_ticket && m.done) HIPCHK(c, hipStreamWaitEvent(c->stream, m.done, 0));
-  p.md5_ticket = -1;
-  return 0;
-}
-
 // Copy device planes of `p` into int16 host planes.
 int download_planes(hevcrecon_ctx *c, const DevPicture &p, int16_t *y, int16_t *cb, int16_t *cr, int stride_y, int stride_c) {
   const SeqInfo &s = c->si;
@@ -464,6 +458,7 @@ void destroy_context(hevcrecon_ctx *c) {
   for (int i = 0; i < kMd5Slots; i++) {
     Md5Slot &m = c->md5_slots[i];
     if (m.dev) hipFree(m.dev);
+    if (m.snap) hipFree(m.snap);
     if (m.host) hipHostFree(m.host);
     if (m.done) hipEventDestroy(m.done);
   }
@@ -913,8 +908,6 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
   const SeqInfo &s = c->si;
   PicJob *jh = ws.jobs_host, *jd = ws.jobs_dev;
   if (c->ring_used[ws.slot]) HIPCHK(c, hipEventSynchronize(c->ring_ev[ws.slot]));
-  for (int i = 0; i < n; i++)
-    if (wait_for_md5_reader(c, c->pics[dst_ids[i]])) return 1;
   int max_tu[4] = {0, 0, 0, 0}, max_small_groups = 0, max_levels = 0, max_mct[3] = {0, 0, 0}, max_mcb = 0;
   bool any_deblock = false, any_sao = false, any_wp = false, any_expand = false;
   for (int i = 0; i < n; i++) {
@@ -1009,12 +1002,17 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
       }
       // pictures that lie back to back in the upload ring travel in one copy (cut into pieces of a few megabytes so
       // that the copy streams share the work)
+      // (in the order of their staging addresses, whatever the order of the batch)
       const size_t kPiece = (size_t)8 << 20;
+      hevcrecon_syntax *stale[HR_MAX_BATCH];  // (on the stack: this path allocates nothing)
+      size_t n_stale = 0;
+      for (int i = 0; i < n; i++)
+        if (syn[i]->dirty) stale[n_stale++] = syn[i];
+      std::sort(stale, stale + n_stale, [](const hevcrecon_syntax *a, const hevcrecon_syntax *b) { return a->up_host < b->up_host; });
       char *run_h = nullptr, *run_d = nullptr;
       size_t run_n = 0;
-      for (int i = 0; i <= n; i++) {
-        hevcrecon_syntax *y = i < n ? syn[i] : nullptr;
-        if (y && !y->dirty) continue;
+      for (size_t i = 0; i <= n_stale; i++) {
+        hevcrecon_syntax *y = i < n_stale ? stale[i] : nullptr;
         if (y && run_n && run_n + y->upload_bytes <= kPiece && y->up_host == run_h + run_n && y->up_dev == run_d + run_n) {
           run_n += y->upload_bytes;
         } else {
@@ -1273,7 +1271,6 @@ extern "C" int hevcrecon_picture_copy(hevcrecon_ctx *c, int dst_pic_id, int src_
   HIPCHK(c, hipSetDevice(c->device));
   if ((int)c->pics.size() <= dst_pic_id) c->pics.resize(dst_pic_id + 1);
   if (alloc_picture(c, c->pics[dst_pic_id])) return 1;
-  if (wait_for_md5_reader(c, c->pics[dst_pic_id])) return 1;
   HIPCHK(c, hipMemcpyAsync(c->pics[dst_pic_id].base, c->pics[src_pic_id].base, c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
   c->pics[dst_pic_id].valid = true;
   c->pics[dst_pic_id].poc = dst_poc;
@@ -1370,33 +1367,43 @@ extern "C" int hevcrecon_picture_md5_submit(hevcrecon_ctx *c, int n, const int *
     if (pic_ids[i] < 0 || pic_ids[i] >= (int)c->pics.size() || !c->pics[pic_ids[i]].valid) return fail(c, "picture is not resident");
   HIPCHK(c, hipSetDevice(c->device));
   if (!c->md5_stream) {
-    HIPCHK(c, hipStreamCreateWithFlags(&c->md5_stream, hipStreamNonBlocking));
+    // lowest priority: a hardware queue of its own (streams of one priority share a few queues, and a hash kernel
+    // runs for milliseconds: nothing of the reconstruction may ever queue up behind one), served when the
+    // reconstruction kernels leave room
+    int least = 0, greatest = 0;
+    HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(c, hipStreamCreateWithPriority(&c->md5_stream, hipStreamNonBlocking, least));
     HIPCHK(c, hipEventCreateWithFlags(&c->md5_fork, hipEventDisableTiming));
   }
   Md5Slot &m = c->md5_slots[c->md5_next % kMd5Slots];
   if (m.ticket >= 0) return fail(c, "too many picture hashes in flight: collect earlier tickets with hevcrecon_picture_md5_poll or _wait first");
   const size_t desc_bytes = align_up(sizeof(Md5Plane) * 3 * n, 256), dig_bytes = (size_t)48 * n;
-  if (m.cap < (size_t)n) {
+  if (m.cap < (size_t)n || m.snap_pic_bytes != c->pic_bytes) {
     if (m.dev) hipFree(m.dev);
+    if (m.snap) hipFree(m.snap);
     if (m.host) hipHostFree(m.host);
-    m.dev = nullptr;
+    m.dev = m.snap = nullptr;
     m.host = nullptr;
     m.cap = 0;
-    const size_t cap = std::max<size_t>(n, 16);
-    const size_t bytes = align_up(sizeof(Md5Plane) * 3 * cap, 256) + 48 * cap;
+    const size_t cap = std::max<size_t>(n, 4);
+    const size_t bytes = align_up(sizeof(Md5Plane) * 3 * cap, 256) + 48 * cap + 64;
     HIPCHK(c, hipMalloc(&m.dev, bytes));
+    HIPCHK(c, hipMalloc(&m.snap, cap * c->pic_bytes));
     HIPCHK(c, hipHostMalloc((void **)&m.host, bytes));
     m.cap = cap;
+    m.snap_pic_bytes = c->pic_bytes;
   }
   if (!m.done) HIPCHK(c, hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
   const SeqInfo &s = c->si;
   const size_t pb = c->pel_bytes;
   Md5Plane *d = (Md5Plane *)m.host;  // descriptors, then (after the copy back) the digests, in the slot's pinned buffer
   for (int i = 0; i < n; i++) {
-    const DevPicture &p = c->pics[pic_ids[i]];
-    d[i] = Md5Plane{p.p[0], (uint32_t)(s.w * pb), (uint32_t)s.h, (uint32_t)(s.stride_y * pb), 0};
-    d[n + 2 * i] = Md5Plane{p.p[1], (uint32_t)(s.cw * pb), (uint32_t)s.ch, (uint32_t)(s.stride_c * pb), 0};
-    d[n + 2 * i + 1] = Md5Plane{p.p[2], (uint32_t)(s.cw * pb), (uint32_t)s.ch, (uint32_t)(s.stride_c * pb), 0};
+    // the pictures as they are when everything queued so far has run, copied in the kernels' stream
+    char *snap = (char *)m.snap + (size_t)i * c->pic_bytes;
+    HIPCHK(c, hipMemcpyAsync(snap, c->pics[pic_ids[i]].base, c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
+    d[i] = Md5Plane{snap + c->plane_off[0], (uint32_t)(s.w * pb), (uint32_t)s.h, (uint32_t)(s.stride_y * pb), 0};
+    d[n + 2 * i] = Md5Plane{snap + c->plane_off[1], (uint32_t)(s.cw * pb), (uint32_t)s.ch, (uint32_t)(s.stride_c * pb), 0};
+    d[n + 2 * i + 1] = Md5Plane{snap + c->plane_off[2], (uint32_t)(s.cw * pb), (uint32_t)s.ch, (uint32_t)(s.stride_c * pb), 0};
   }
   HIPCHK(c, hipEventRecord(c->md5_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->md5_stream, c->md5_fork, 0));
@@ -1405,10 +1412,11 @@ extern "C" int hevcrecon_picture_md5_submit(hevcrecon_ctx *c, int n, const int *
   hr_launch_md5((const Md5Plane *)m.dev, 3 * n, dig_dev, c->md5_stream);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(m.host + desc_bytes, dig_dev, dig_bytes, hipMemcpyDeviceToHost, c->md5_stream));
+  // the error words of the kernels that wrote the pictures (they ran before the copies above) travel with the digests
+  HIPCHK(c, hipMemcpyAsync(m.host + desc_bytes + dig_bytes, c->error_flag_dev, 64, hipMemcpyDeviceToHost, c->md5_stream));
   HIPCHK(c, hipEventRecord(m.done, c->md5_stream));
   m.ticket = c->md5_next++;
   m.n = n;
-  for (int i = 0; i < n; i++) c->pics[pic_ids[i]].md5_ticket = m.ticket;
   *ticket = m.ticket;
   return 0;
 }
@@ -1437,12 +1445,9 @@ static int md5_collect(hevcrecon_ctx *c, int64_t ticket, bool block, int *done, 
   }
   m.ticket = -1;
   if (done) *done = 1;
-  // the kernels that wrote the pictures ran before the hash kernel: their error words are final
-  if (c->error_host) {
-    HIPCHK(c, hipMemcpyAsync(c->error_host, c->error_flag_dev, 64, hipMemcpyDeviceToHost, c->md5_stream));
-    HIPCHK(c, hipStreamSynchronize(c->md5_stream));
-    if (c->error_host[0]) return check_device_errors(c);
-  }
+  int32_t err0;
+  std::memcpy(&err0, dig_host + (size_t)48 * n, 4);
+  if (err0) return check_device_errors(c);  // reads the words again (waiting for the kernels' stream) and makes the message
   return 0;
 }
 

@@ -2388,62 +2388,116 @@ __global__ __launch_bounds__(256) void k_output(const pel_t *src, int stride, ui
 // ------------------------------------------------------------------------------------------------
 // k_md5: the picture hash of the reference (calcMD5, TLibCommon/TComPicYuvMD5.cpp:188-213; MD5 itself: RFC 1321,
 // the reference's copy is libmd5/libmd5.c): every plane's samples in raster order, one byte per sample up to 8 bits,
-// else two bytes, low byte first -- which is how the planes lie in memory, row padding aside.  One lane per plane.
+// else two bytes, low byte first -- which is how the planes lie in memory, row padding aside.
+// MD5 is one serial chain per plane (64 dependent steps per 64-byte block), so a plane is one lane's work: lane 0 of
+// the plane's wave.  The other 63 lanes fetch for it: the wave reads 64 blocks at a time (lane = block, all 16 words
+// of a block in flight at once), parks them in LDS while lane 0 works through the previous 64, and lane 0 takes its
+// message words from LDS a block ahead -- the chain never waits for memory.
 // ------------------------------------------------------------------------------------------------
-__constant__ unsigned kMd5K[64] = {
-    0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1,
-    0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453,
-    0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a, 0xfffa3942,
-    0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05,
-    0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d,
-    0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
-__constant__ uint8_t kMd5S[16] = {7, 12, 17, 22, 5, 9, 14, 20, 4, 11, 16, 23, 6, 10, 15, 21};
+#ifdef HEVCRECON_EMULATE
+__device__ __forceinline__ unsigned hr_rotl(unsigned v, int sh) { return (v << sh) | (v >> (32 - sh)); }
+#else
+__device__ __forceinline__ unsigned hr_rotl(unsigned v, int sh) { return __builtin_amdgcn_alignbit(v, v, 32 - sh); }  // one v_alignbit_b32
+#endif
+struct Md5Tables {
+  unsigned k[64];
+  int s[64], g[64];
+};
+constexpr Md5Tables make_md5_tables() {
+  const unsigned k[64] = {
+      0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1,
+      0x895cd7be, 0x6b901122, 0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453,
+      0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6, 0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a, 0xfffa3942,
+      0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60, 0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05,
+      0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039, 0x655b59c3, 0x8f0ccc92, 0xffeff47d,
+      0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391};
+  const int sh[16] = {7, 12, 17, 22, 5, 9, 14, 20, 4, 11, 16, 23, 6, 10, 15, 21};
+  Md5Tables t = {};
+  for (int i = 0; i < 64; i++) {
+    t.k[i] = k[i];
+    t.s[i] = sh[(i >> 4) * 4 + (i & 3)];
+    t.g[i] = i < 16 ? i : i < 32 ? (5 * i + 1) & 15 : i < 48 ? (3 * i + 5) & 15 : (7 * i) & 15;
+  }
+  return t;
+}
+
+// Word j of message block blk of a plane: its bytes, then the padding of RFC 1321 (0x80, zeros, the length in bits).
+__device__ __forceinline__ void md5_block_words(const Md5Plane &pl, unsigned len, unsigned nblocks, unsigned blk, unsigned w[16]) {
+  unsigned pos = blk * 64u;
+  unsigned row = pos / pl.row_bytes, col = pos - row * pl.row_bytes;  // (row_bytes is a multiple of 4: a word never straddles rows)
+#pragma unroll
+  for (int j = 0; j < 16; j++, pos += 4) {
+    unsigned v = 0;
+    if (pos < len) {
+      v = *(const HR_GLOBAL unsigned *)((const HR_GLOBAL char *)pl.base + (size_t)row * pl.stride_bytes + col);
+      col += 4;
+      if (col == pl.row_bytes) col = 0, row++;
+    } else if (pos == len) {
+      v = 0x80u;
+    } else if (blk == nblocks - 1 && j == 14) {
+      v = len << 3;
+    } else if (blk == nblocks - 1 && j == 15) {
+      v = len >> 29;
+    }
+    w[j] = v;
+  }
+}
 
 __global__ __launch_bounds__(64) void k_md5(const Md5Plane *planes, int n, uint8_t *digests) {
-  const int idx = blockIdx.x * 64 + threadIdx.x;
+  constexpr Md5Tables T = make_md5_tables();
+  __shared__ __attribute__((aligned(16))) unsigned buf[2][64][16];
+  const int lane = threadIdx.x;
+  const int idx = blockIdx.x;
   if (idx >= n) return;
   const Md5Plane pl = planes[idx];
-  const unsigned long long len = (unsigned long long)pl.row_bytes * pl.rows;
-  const unsigned long long nblocks = (len + 8) / 64 + 1;
+  const unsigned len = pl.row_bytes * pl.rows;  // at most 8192 x 8192 samples of two bytes
+  const unsigned nblocks = (len + 8) / 64 + 1;
+  const unsigned nchunks = (nblocks + 63) / 64;
   unsigned a0 = 0x67452301u, b0 = 0xefcdab89u, c0 = 0x98badcfeu, d0 = 0x10325476u;
-  unsigned row = 0, col = 0;  // position of the next message word inside the plane
-  for (unsigned long long blk = 0; blk < nblocks; blk++) {
-    unsigned m[16];
+  unsigned w[16];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const unsigned long long pos = blk * 64 + 4 * j;
-      unsigned w = 0;
-      if (pos < len) {
-        w = *(const unsigned *)((const char *)pl.base + (size_t)row * pl.stride_bytes + col);
-        col += 4;
-        if (col == pl.row_bytes) col = 0, row++;
-      } else if (pos == len) {
-        w = 0x80u;
-      } else if (blk == nblocks - 1 && j == 14) {
-        w = (unsigned)(len << 3);
-      } else if (blk == nblocks - 1 && j == 15) {
-        w = (unsigned)((len << 3) >> 32);
+  for (int j = 0; j < 16; j++) w[j] = 0;
+  if ((unsigned)lane < nblocks) md5_block_words(pl, len, nblocks, lane, w);
+  for (unsigned chunk = 0; chunk < nchunks; chunk++) {
+    unsigned(*cur)[16] = buf[chunk & 1];
+#pragma unroll
+    for (int j = 0; j < 16; j += 4) *(uint4 *)&cur[lane][j] = make_uint4(w[j], w[j + 1], w[j + 2], w[j + 3]);
+    hr_wave_sync();
+    // the next 64 blocks are requested now and arrive while lane 0 works
+    const unsigned nb = (chunk + 1) * 64 + lane;
+    if (chunk + 1 < nchunks && nb < nblocks) md5_block_words(pl, len, nblocks, nb, w);
+    if (lane == 0) {
+      const unsigned left = nblocks - chunk * 64, here = left < 64u ? left : 64u;
+      unsigned m[16], mn[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) m[j] = cur[0][j];
+      for (unsigned b = 0; b < here; b++) {
+        const unsigned bn = b + 1 < here ? b + 1 : b;
+#pragma unroll
+        for (int j = 0; j < 16; j++) mn[j] = cur[bn][j];
+        unsigned a = a0, bb = b0, c = c0, d = d0;
+#pragma unroll
+        for (int i = 0; i < 64; i++) {
+          unsigned f;
+          if (i < 16) f = d ^ (bb & (c ^ d));
+          else if (i < 32) f = c ^ (d & (bb ^ c));
+          else if (i < 48) f = bb ^ c ^ d;
+          else f = c ^ (bb | ~d);
+          f = f + (a + T.k[i] + m[T.g[i]]);
+          a = d, d = c, c = bb;
+          bb = bb + hr_rotl(f, T.s[i]);
+        }
+        a0 += a, b0 += bb, c0 += c, d0 += d;
+#pragma unroll
+        for (int j = 0; j < 16; j++) m[j] = mn[j];
       }
-      m[j] = w;
     }
-    unsigned a = a0, b = b0, c = c0, d = d0;
-#pragma unroll
-    for (int i = 0; i < 64; i++) {
-      unsigned f;
-      int g;
-      if (i < 16) f = (b & c) | (~b & d), g = i;
-      else if (i < 32) f = (d & b) | (~d & c), g = (5 * i + 1) & 15;
-      else if (i < 48) f = b ^ c ^ d, g = (3 * i + 5) & 15;
-      else f = c ^ (b | ~d), g = (7 * i) & 15;
-      f = f + a + kMd5K[i] + m[g];
-      a = d, d = c, c = b;
-      const int sh = kMd5S[(i >> 4) * 4 + (i & 3)];
-      b = b + ((f << sh) | (f >> (32 - sh)));
-    }
-    a0 += a, b0 += b, c0 += c, d0 += d;
+    hr_wave_sync();
   }
-  unsigned *out = (unsigned *)(digests + (size_t)idx * 16);
-  out[0] = a0, out[1] = b0, out[2] = c0, out[3] = d0;
+  if (lane == 0) {
+    unsigned *out = (unsigned *)(digests + (size_t)idx * 16);
+    out[0] = a0, out[1] = b0, out[2] = c0, out[3] = d0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2543,7 +2597,7 @@ void hr_launch_intra(const PicJob *jobs, const SeqInfo &s, const unsigned *list,
 }
 
 void hr_launch_md5(const Md5Plane *planes, int n, uint8_t *digests, hipStream_t st) {
-  LAUNCH(k_md5, dim3((n + 63) / 64), dim3(64), st, planes, n, digests);
+  LAUNCH(k_md5, dim3(n), dim3(64), st, planes, n, digests);  // one wave per plane
 }
 
 void hr_launch(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t st, int arg, int arg2) {

@@ -324,8 +324,9 @@ int hevcrecon_picture_md5_batch(hevcrecon_ctx *ctx, int n, const int *pic_ids, u
  * is queued on a stream of the context's own, behind everything queued so far and beside the reconstruction of later
  * pictures; *ticket names the request.  hevcrecon_picture_md5_poll sets *done and fills digests (n x 3 x 16 bytes, as
  * above) once the digests are back, hevcrecon_picture_md5_wait blocks until then; either collects a ticket once.  Up
- * to 64 tickets may be outstanding.  A later call that would overwrite one of the pictures (reconstruction into its
- * id, hevcrecon_picture_copy, _upload, _release) is ordered behind the hash kernel by the engine. */
+ * to 64 tickets may be outstanding.  The pictures are hashed as they are when everything queued before the call has
+ * run: the engine hashes copies of its own (made on the device, in order with the reconstruction kernels), so the
+ * caller may reuse the picture ids at once, as a decoder does with its picture buffers. */
 int hevcrecon_picture_md5_submit(hevcrecon_ctx *ctx, int n, const int *pic_ids, int64_t *ticket);
 int hevcrecon_picture_md5_poll(hevcrecon_ctx *ctx, int64_t ticket, int *done, uint8_t *digests);
 int hevcrecon_picture_md5_wait(hevcrecon_ctx *ctx, int64_t ticket, uint8_t *digests);

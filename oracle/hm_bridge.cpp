@@ -162,8 +162,9 @@ struct Bridge {
   hevcrecon_ctx *ctx;
   // Packed pictures in flight: a syntax object is rewritten only when the GPU is done with the picture it held, so
   // the decoder rotates over a few of them and never waits for that.
-  enum { kSyntaxObjects = 4 };
-  hevcrecon_syntax *syns[kSyntaxObjects];
+  enum { kMaxSyntaxObjects = 32 };
+  int kSyntaxObjects;  // HEVCRECON_DEPTH (default 4): pictures the host may run ahead of the GPU
+  hevcrecon_syntax *syns[kMaxSyntaxObjects];
   int syn_pos;
   hevcrecon_syntax *syn;  // the one the picture being parsed is packed into
   bool device_hash;
@@ -173,6 +174,8 @@ struct Bridge {
   Bridge() : mode(MODE_REF), dump(NULL), dump_planes(false), header_written(false), ctx(NULL), syn_pos(0), syn(NULL), device_hash(false) {
     memset(syns, 0, sizeof(syns));
     memset(&api, 0, sizeof(api));
+    kSyntaxObjects = getenv("HEVCRECON_DEPTH") ? atoi(getenv("HEVCRECON_DEPTH")) : 4;
+    if (kSyntaxObjects < 1 || kSyntaxObjects > kMaxSyntaxObjects) kSyntaxObjects = 4;
     tm.on = getenv("HEVCRECON_TIMING") && atoi(getenv("HEVCRECON_TIMING"));
     tm.t_process = now();
     const char *m = getenv("HEVCRECON_MODE");

@@ -156,6 +156,8 @@ inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::m
 inline hipError_t hipStreamCreate(hipStream_t *s) { g_emu_allocations++; *s = nullptr; return hipSuccess; }
 enum { hipStreamNonBlocking = 1 };
 inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { g_emu_allocations++; *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { g_emu_allocations++; *s = nullptr; return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 0; *greatest = -1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
