@@ -131,9 +131,14 @@ def cpu_baseline(seconds_target=10.0):
             "sample": "first %d pictures of the 1080p RA stream through oracle/recon_ref.c (reconstruction only), %.1f s" % (len(seq.pictures), dt)}
 
 
-def _bridge_env(device, hash_mode):
+HUB_BINARY = os.path.join(ROOT, "hevc_amd", "hevcrecon_hub")
+
+
+def _bridge_env(device, hash_mode, hub=None):
     from hevc_amd import abi
 
+    if hub is not None:  # the decoder never opens the GPU: it hands its packed pictures to the hub process
+        return dict(os.environ, HEVCRECON_MODE="hub", HEVCRECON_HUB=hub, HEVCRECON_LIB=abi.LIB_PATH, HEVCRECON_TIMING="1")
     env = dict(os.environ, HEVCRECON_MODE="engine", HEVCRECON_LIB=abi.LIB_PATH, HEVCRECON_DEVICE=str(device), HEVCRECON_HASH=hash_mode,
                HEVCRECON_TIMING="1")
     if os.environ.get("HEVCRECON_E2E_HWQ"):
@@ -181,16 +186,50 @@ def end_to_end(device, n_proc, loops=8):
             with open(looped, "wb") as f:
                 for _ in range(loops):
                     f.write(one)
+            stages = os.environ.get("HEVCRECON_E2E_STAGES", "direct,hub,host,one").split(",")
+
+            launched = [0]
+
+            def start(bits, env):
+                """A decoder process writing into files of its own (a pipe that nobody drains stalls the decoder as soon as
+                it holds 64 KB of status lines)."""
+                k = launched[0]
+                launched[0] += 1
+                fo, fe = open(os.path.join(tmp, "out_%d" % k), "wb"), open(os.path.join(tmp, "err_%d" % k), "wb")
+                p = subprocess.Popen([BRIDGE_DECODER, "-b", bits], env=env, stdout=fo, stderr=fe)
+                p.files = (fo, fe)
+                return p
+
+            def run_all(procs, limit=240):
+                """stdout / stderr of every decoder; a decoder that does not finish in time is killed (and fails the stage)"""
+                deadline = time.time() + limit
+                res = []
+                for p in procs:
+                    try:
+                        p.wait(timeout=max(1.0, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        p.wait()
+                    for f in p.files:
+                        f.close()
+                    res.append((open(p.files[0].name, "rb").read(), open(p.files[1].name, "rb").read()))
+                return res
+
             env = _bridge_env(device, "device")
+            progress("end to end: %d decoders, each with a GPU context of its own" % n_proc)
             t0 = time.time()
-            procs = [subprocess.Popen([BRIDGE_DECODER, "-b", looped], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for _ in range(n_proc)]
-            res = [p.communicate() for p in procs]
+            procs = [start(looped if "direct" in stages else RA_BITSTREAM, env) for _ in range(n_proc)]
+            res = run_all(procs)
+            if "direct" not in stages:
+                loops_direct = 1
+            else:
+                loops_direct = loops
             wall = time.time() - t0
             ts = []
             for p, (so, se) in zip(procs, res):
                 t = _bridge_timing(se)
-                if p.returncode != 0 or so.count(b"(OK)") != 60 * loops or t is None:
-                    raise RuntimeError("a concurrent decoder failed (exit %d, %d of %d pictures OK): %s" % (p.returncode, so.count(b"(OK)"), 60 * loops, se[-300:]))
+                if p.returncode != 0 or so.count(b"(OK)") != 60 * loops_direct or t is None:
+                    raise RuntimeError("a concurrent decoder failed (exit %d, %d of %d pictures OK): %s" % (p.returncode, so.count(b"(OK)"), 60 * loops_direct, se[-300:]))
                 ts.append(t)
             span = max(t["wall_last"] for t in ts) - min(t["wall_first"] for t in ts)
             frames = sum(t["pictures"] for t in ts)
@@ -201,17 +240,44 @@ def end_to_end(device, n_proc, loops=8):
                 "hash": "device", "pictures_per_hash_request": round(frames / max(1, sum(t["hash_batches"] for t in ts)), 1),
                 "per_picture_ms": _per_picture_ms(ts)}
             out["packer_us_per_picture_c"] = round(sum(t["pack_s"] + t["finish_s"] for t in ts) / frames * 1e6, 1)
+            # the same decoders behind ONE process that owns the GPU (hevc_amd/hevcrecon_hub): the decoder processes pack on
+            # their cores and never open the device; the hub reconstructs what all of them have ready as one batch
+            if os.path.exists(HUB_BINARY) and "hub" in stages:
+                progress("end to end: %d decoders behind one hub process" % n_proc)
+                hub_name = "bench_%d" % os.getpid()
+                hub = subprocess.Popen([HUB_BINARY, "--name", hub_name, "--device", str(device), "--idle-exit", "1"], stderr=subprocess.PIPE)
+                procs = [start(looped, _bridge_env(device, "device", hub_name)) for _ in range(n_proc)]
+                res = run_all(procs, 120)
+                try:
+                    hub_err = hub.communicate(timeout=30)[1].decode("latin1")
+                except subprocess.TimeoutExpired:
+                    hub.kill()
+                    hub_err = "hub did not leave"
+                ts = [_bridge_timing(se) for _, se in res]
+                if all(p.returncode == 0 for p in procs) and all(t is not None for t in ts) and all(so.count(b"(OK)") == 60 * loops for so, _ in res):
+                    span = max(t["wall_last"] for t in ts) - min(t["wall_first"] for t in ts)
+                    frames = sum(t["pictures"] for t in ts)
+                    import re
+
+                    m = re.search(r"\(([0-9.]+) per batch\)", hub_err)
+                    progress(hub_err.strip().replace("\n", " | "))
+                    out["concurrent_through_hub"] = {"processes": n_proc, "gpu_processes": 1, "frames": frames, "frames_per_s": round(frames / span, 1),
+                                                     "pictures_per_batch": float(m.group(1)) if m else None, "hash": "device",
+                                                     "per_picture_ms": _per_picture_ms(ts)}
+                else:
+                    out["concurrent_through_hub"] = {"error": (hub_err + " ".join(se.decode("latin1")[-200:] for _, se in res if se))[-400:]}
             # the same with every picture fetched and hashed by the reference on the host thread
-            procs = [subprocess.Popen([BRIDGE_DECODER, "-b", looped], env=_bridge_env(device, "host"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-                     for _ in range(n_proc)]
-            res = [p.communicate() for p in procs]
+            progress("end to end: %d decoders that fetch and hash on the host" % n_proc)
+            procs = [start(looped if "host" in stages else RA_BITSTREAM, _bridge_env(device, "host")) for _ in range(n_proc)]
+            res = run_all(procs)
             ts = [_bridge_timing(se) for _, se in res]
-            if all(p.returncode == 0 for p in procs) and all(t is not None for t in ts) and all(so.count(b"(OK)") == 60 * loops for so, _ in res):
+            if "host" in stages and all(p.returncode == 0 for p in procs) and all(t is not None for t in ts) and all(so.count(b"(OK)") == 60 * loops for so, _ in res):
                 span = max(t["wall_last"] for t in ts) - min(t["wall_first"] for t in ts)
                 frames = sum(t["pictures"] for t in ts)
                 out["concurrent_host_hash"] = {"processes": n_proc, "frames": frames, "frames_per_s": round(frames / span, 1),
                                                "per_picture_ms": _per_picture_ms(ts)}
             # one process alone
+            progress("end to end: one decoder alone")
             single = {}
             for name, hash_mode in (("device_hash", "device"), ("host_hash", "host")):
                 r = subprocess.run([BRIDGE_DECODER, "-b", RA_BITSTREAM], env=_bridge_env(device, hash_mode), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -351,7 +417,9 @@ def main():
     ap.add_argument("--extras", default="e2e,handover,fewer,stagger",
                     help="which side measurements to run (comma separated): e2e (decoder processes through the CLI), handover, "
                          "fewer (1 and 8 streams), stagger (every stream at its own position)")
-    ap.add_argument("--upload-ring", action="store_true", help="stage all packed pictures in the context's upload ring (coalesced hand-over copies)")
+    ap.add_argument("--no-upload-ring", dest="upload_ring", action="store_false",
+                    help="every packed picture in pinned buffers of its own instead of the context's upload ring (one copy command per picture "
+                         "instead of a few per batch)")
     ap.add_argument("--check-two-streams-only", action="store_true",
                     help="parity pass without the device hash of every stream (profiling runs: keeps k_md5 out of the kernel statistics)")
     ap.add_argument("--e2e-procs", type=int, default=0,

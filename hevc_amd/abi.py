@@ -145,7 +145,18 @@ EXPORTS = {
     "hevcrecon_picture_download": (C.c_int, [_P, C.c_int, _I16P, _I16P, _I16P, C.c_int, C.c_int]),
     "hevcrecon_picture_download_file": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "hevcrecon_picture_md5_batch": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "hevcrecon_syntax_export": (C.c_int, [_P, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "hevcrecon_syntax_import": (C.c_int, [_P, C.c_void_p, C.c_int64]),
+    "hevcrecon_hub_connect": (C.c_int, [C.c_char_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "hevcrecon_hub_pic_id_base": (C.c_int, [_P]),
+    "hevcrecon_hub_submit": (C.c_int, [_P, _P, C.c_int]),
+    "hevcrecon_hub_copy": (C.c_int, [_P, C.c_int, C.c_int, C.c_int]),
+    "hevcrecon_hub_poll": (C.c_int, [_P, C.POINTER(C.c_int), C.c_void_p]),
+    "hevcrecon_hub_wait": (C.c_int, [_P, C.c_void_p]),
+    "hevcrecon_hub_error": (C.c_char_p, [_P]),
+    "hevcrecon_hub_disconnect": (None, [_P]),
     "hevcrecon_picture_md5_submit": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "hevcrecon_picture_md5_submit_in_place": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "hevcrecon_picture_md5_poll": (C.c_int, [_P, C.c_int64, C.POINTER(C.c_int), C.c_void_p]),
     "hevcrecon_picture_md5_wait": (C.c_int, [_P, C.c_int64, C.c_void_p]),
     "hevcrecon_debug_keep_stages": (C.c_int, [_P, C.c_int]),

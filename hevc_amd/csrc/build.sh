@@ -10,6 +10,10 @@ mkdir -p "$here/obj"
 "$HIPCC" $FLAGS -c "$here/kernels.hip" -o "$here/obj/kernels.o" &
 "$HIPCC" $FLAGS -x hip -c "$here/engine.cpp" -o "$here/obj/engine.o" &
 g++ -O2 -std=c++17 -fPIC -Wall -c "$here/packer.cpp" -o "$here/obj/packer.o" &
+g++ -O2 -std=c++17 -fPIC -Wall -c "$here/hub_client.cpp" -o "$here/obj/hub_client.o" &
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "$here/obj/kernels.o" "$here/obj/engine.o" "$here/obj/packer.o"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "$here/obj/kernels.o" "$here/obj/engine.o" "$here/obj/packer.o" "$here/obj/hub_client.o" -lrt
 echo "built $out"
+# the process that owns the GPU when many decoder processes share it (hub.cpp): the public C ABI only
+g++ -O2 -std=c++17 -Wall "$here/hub.cpp" -o "$here/../hevcrecon_hub" -L"$here/.." -lhevcrecon -Wl,-rpath,'$ORIGIN' -lrt
+echo "built $here/../hevcrecon_hub"

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <type_traits>
 #include <mutex>
 #include <string>
 #include <deque>
@@ -114,7 +115,8 @@ struct Md5Slot {
   void *dev = nullptr;
   uint8_t *host = nullptr;
   void *snap = nullptr;  // n pictures, pic_bytes apart
-  size_t cap = 0;        // pictures the buffers hold
+  size_t cap = 0;        // pictures the descriptor and digest buffers hold
+  size_t snap_cap = 0;   // pictures the copies hold
   size_t snap_pic_bytes = 0;
   hipEvent_t done = nullptr;
 };
@@ -178,11 +180,15 @@ struct hevcrecon_ctx {
   int32_t *error_flag_dev = nullptr;  // 16 words the kernels raise when they meet something the packer should have refused
   int32_t *error_host = nullptr;      // pinned: where hevcrecon_synchronize reads them
   int longest_intra_wait = 0;         // polls of the longest wait of an intra CTU for a neighbour seen so far (word 8)
+  std::vector<void *> retired;  // device buffers that were outgrown: freed when the context is idle
+  size_t largest_syntax = 0;    // device bytes of the largest packed picture so far
   void *dl_host = nullptr;  // pinned staging for downloads / uploads
   void *out_dev = nullptr;  // a picture in file format (hevcrecon_picture_download_file)
   // hevcrecon_picture_md5_submit: a stream of its own beside the reconstruction kernels, tickets in flight
-  hipStream_t md5_stream = nullptr;
-  hipEvent_t md5_fork = nullptr;  // recorded on the kernels' stream, waited for by md5_stream
+  // (a hash kernel runs for milliseconds whatever it hashes: requests go round a few streams so that several overlap)
+  hipStream_t md5_streams[4] = {};
+  hipStream_t md5_stream = nullptr;  // the first of them; also says that they exist
+  hipEvent_t md5_fork = nullptr;  // recorded on the kernels' stream, waited for by the hash streams
   Md5Slot md5_slots[kMd5Slots];
   int64_t md5_next = 0;
   size_t out_cap = 0;
@@ -450,11 +456,14 @@ void destroy_context(hevcrecon_ctx *c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->have_copy_streams)
     for (int i = 0; i < kCopyStreams; i++) hipStreamSynchronize(c->copy_stream[i]);
-  if (c->md5_stream) hipStreamSynchronize(c->md5_stream);
+  if (c->md5_stream)
+    for (int i = 0; i < 4; i++) hipStreamSynchronize(c->md5_streams[i]);
   {  // the fixed work area has no user any more once this context's stream has drained
     std::lock_guard<std::mutex> lock(g_copy_mutex);
     if (c->device >= 0 && c->device < 64 && g_scratch_user[c->device].ctx == c) g_scratch_user[c->device] = ScratchUser{nullptr, nullptr};
   }
+  for (size_t i = 0; i < c->retired.size(); i++) hipFree(c->retired[i]);
+  c->retired.clear();
   for (int i = 0; i < kMd5Slots; i++) {
     Md5Slot &m = c->md5_slots[i];
     if (m.dev) hipFree(m.dev);
@@ -463,7 +472,8 @@ void destroy_context(hevcrecon_ctx *c) {
     if (m.done) hipEventDestroy(m.done);
   }
   if (c->md5_fork) hipEventDestroy(c->md5_fork);
-  if (c->md5_stream) hipStreamDestroy(c->md5_stream);
+  if (c->md5_stream)
+    for (int i = 0; i < 4; i++) hipStreamDestroy(c->md5_streams[i]);
   drain_intervals(c);
   for (size_t i = 0; i < c->pics.size(); i++) free_picture(c->pics[i]);
   for (size_t i = 0; i < c->work.size(); i++) free_picture(c->work[i]);
@@ -559,7 +569,8 @@ extern "C" int hevcrecon_sequence_init(hevcrecon_ctx *c, const hevcrecon_seq_par
   if (!seq_params_ok(*sp, why)) return fail(c, why);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->md5_stream) HIPCHK(c, hipStreamSynchronize(c->md5_stream));
+  if (c->md5_stream)
+    for (int i = 0; i < 4; i++) HIPCHK(c, hipStreamSynchronize(c->md5_streams[i]));
   for (size_t i = 0; i < c->pics.size(); i++) free_picture(c->pics[i]);
   for (size_t i = 0; i < c->work.size(); i++) free_picture(c->work[i]);
   for (size_t i = 0; i < c->work_resi.size(); i++) {
@@ -631,13 +642,9 @@ extern "C" int hevcrecon_syntax_begin(hevcrecon_syntax *s) {
     s->si = s->ctx->si;
     // the previous upload must have left the staging buffer, and the kernels that read the previous picture's
     // device copy must be done, before either is rewritten
-    if (s->uploaded) {
-      if (s->upload_seq > s->ctx->upload_synced) {
-        for (int k = 0; k < kCopyStreams; k++) hipStreamSynchronize(s->ctx->copy_stream[k]);
-        s->ctx->upload_synced = s->ctx->upload_no - 1;
-      }
-      if (s->last_batch >= 0) hipEventSynchronize(s->ctx->batch_ev[s->last_batch % kRing]);
-    }
+    // (copies are queued with the first batch that uses the picture and that batch's kernels wait for them: once
+    // the last batch that read the picture is done, so is every copy out of its staging buffer)
+    if (s->uploaded && s->last_batch >= 0) hipEventSynchronize(s->ctx->batch_ev[s->last_batch % kRing]);
   }
   ring_release(s);  // nothing reads the previous picture any more (waited for above)
   s->uploaded = false;
@@ -707,13 +714,9 @@ static int queue_upload(hevcrecon_syntax *s) {
 
 extern "C" const char *hevcrecon_syntax_last_error(const hevcrecon_syntax *s) { return s ? s->err.c_str() : "no syntax object"; }
 
-extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_params *pp) {
-  if (!s || !pp) return 1;
-  if (!s->pk.finish(pp)) {
-    s->err = s->pk.error;
-    return fail(s->ctx, s->pk.error);
-  }
-  if (!s->ctx) return 0;  // detached: host-side packing only
+// The packed picture in s->pk goes into pinned staging (the context's upload ring, or buffers of the object's own) and
+// is marked for its trip to the device.
+static int stage_packed(hevcrecon_syntax *s) {
   hevcrecon_ctx *c = s->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   PackedPicture &k = s->pk;
@@ -742,12 +745,15 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   s->off_rec4 = place((size_t)k.n_rec4 * sizeof(Part4));  // device only: expanded from the runs after the copy
   const size_t total = off;
   if (s->dev_cap < total) {
-    for (int k = 0; k < kCopyStreams; k++) HIPCHK(c, hipStreamSynchronize(c->copy_stream[k]));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (s->dev) hipFree(s->dev);
+    // A larger buffer, sized by the largest picture the context has seen (intra pictures carry several times the lists
+    // of the others, and every object gets one sooner or later).  The old one is not freed here: kernels in flight may
+    // still read it, and freeing waits for the whole device, hash kernels included; it is freed when the context is
+    // idle anyway (hevcrecon_synchronize, hevcrecon_destroy).
+    if (s->dev) c->retired.push_back(s->dev);
     s->dev = nullptr;
     s->dev_cap = 0;
-    const size_t cap = total + total / 4;
+    c->largest_syntax = std::max(c->largest_syntax, total);
+    const size_t cap = c->largest_syntax + c->largest_syntax / 4;
     HIPCHK(c, hipMalloc((void **)&s->dev, cap));
     s->dev_cap = cap;
   }
@@ -783,6 +789,196 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
   std::memcpy(s->up_host + s->off_scal, &k.scaling, sizeof(ScalingTables));
   std::memcpy(s->up_host + s->off_wp, &k.wp, sizeof(WpTables));
   return queue_upload(s);
+}
+
+extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_params *pp) {
+  if (!s || !pp) return 1;
+  if (!s->pk.finish(pp)) {
+    s->err = s->pk.error;
+    return fail(s->ctx, s->pk.error);
+  }
+  if (!s->ctx) return 0;  // detached: host-side packing only
+  return stage_packed(s);
+}
+
+// ---- a packed picture as one block of bytes -----------------------------------------------------
+// What hevcrecon_syntax_finish leaves in a syntax object, flattened so that it can cross a process boundary: a
+// decoder process that never opens the GPU packs into a host-only object and exports; the process that owns the GPU
+// imports into an object of its context and reconstructs.  Position independent, checked on import.
+namespace {
+const uint32_t kBlobMagic = 0x42525648;  // "HVRB"
+const uint32_t kBlobVersion = 1;
+enum { BL_RUNS, BL_RUNOFF, BL_TU0, BL_TU1, BL_TU2, BL_TU3, BL_COEFF, BL_INTRA, BL_ICTU, BL_ROUNDS, BL_WAVE, BL_SAO, BL_CTUI, BL_MCT0, BL_MCT1, BL_MCT2, BL_MCB, BL_SLICES, BL_COUNT };
+struct BlobHeader {
+  uint32_t magic, version;
+  uint64_t total_bytes;
+  SeqInfo seq;
+  hevcrecon_pic_params pp;
+  int64_t coded_coeffs, mc_ref_samples, n_rec4, n_rec4_intra;
+  int32_t max_ref_idx[2];
+  int32_t inter_without_ref, has_bypass, has_pcm, use_scaling, use_wp, pad;
+  uint64_t count[BL_COUNT];  // elements of every array, in the order of the BL_ indices; the arrays follow the tables, each padded to 16 bytes
+  ScalingTables scaling;
+  WpTables wp;
+};
+const size_t kBlobElem[BL_COUNT] = {sizeof(Part4), 4, sizeof(TuItem), sizeof(TuItem), sizeof(TuItem), sizeof(TuItem), 4, sizeof(IntraItem), sizeof(IntraCtu), 2, 4,
+                                    sizeof(SaoCtu), sizeof(CtuInfo), sizeof(McTile), sizeof(McTile), sizeof(McTile), sizeof(McBlk), sizeof(hevcrecon_slice_params)};
+size_t blob_header_bytes() { return align_up(sizeof(BlobHeader), 16); }
+template <class T> const void *vec_data(const std::vector<T> &v) { return v.data(); }
+}  // namespace
+
+extern "C" int hevcrecon_syntax_export(const hevcrecon_syntax *s, void *dst, int64_t cap, int64_t *bytes) {
+  if (!s || !bytes) return 1;
+  const PackedPicture &k = s->pk;
+  if (!k.finished) return 1;
+  const void *src[BL_COUNT] = {vec_data(k.runs), vec_data(k.ctu_run_off), vec_data(k.tu[0]), vec_data(k.tu[1]), vec_data(k.tu[2]), vec_data(k.tu[3]),
+                               vec_data(k.coeff), vec_data(k.intra), vec_data(k.ictu), vec_data(k.rounds), vec_data(k.wave_off), vec_data(k.sao),
+                               vec_data(k.ctu_info), vec_data(k.mc_tile[0]), vec_data(k.mc_tile[1]), vec_data(k.mc_tile[2]), vec_data(k.mc_blk),
+                               vec_data(k.slices)};
+  const size_t cnt[BL_COUNT] = {k.runs.size(), k.ctu_run_off.size(), k.tu[0].size(), k.tu[1].size(), k.tu[2].size(), k.tu[3].size(), k.coeff.size(),
+                                k.intra.size(), k.ictu.size(), k.rounds.size(), k.wave_off.size(), k.sao.size(), k.ctu_info.size(), k.mc_tile[0].size(),
+                                k.mc_tile[1].size(), k.mc_tile[2].size(), k.mc_blk.size(), k.slices.size()};
+  size_t total = blob_header_bytes();
+  for (int i = 0; i < BL_COUNT; i++) total += align_up(cnt[i] * kBlobElem[i], 16);
+  *bytes = (int64_t)total;
+  if (!dst) return 0;  // size query
+  if (cap < (int64_t)total) return 1;
+  BlobHeader h;
+  std::memset(&h, 0, sizeof(h));
+  h.magic = kBlobMagic;
+  h.version = kBlobVersion;
+  h.total_bytes = total;
+  h.seq = k.seq;
+  h.pp = k.pp;
+  h.coded_coeffs = k.coded_coeffs;
+  h.mc_ref_samples = k.mc_ref_samples;
+  h.n_rec4 = k.n_rec4;
+  h.n_rec4_intra = k.n_rec4_intra;
+  h.max_ref_idx[0] = k.max_ref_idx[0];
+  h.max_ref_idx[1] = k.max_ref_idx[1];
+  h.inter_without_ref = k.inter_without_ref;
+  h.has_bypass = k.has_bypass;
+  h.has_pcm = k.has_pcm;
+  h.use_scaling = k.use_scaling;
+  h.use_wp = k.use_wp;
+  for (int i = 0; i < BL_COUNT; i++) h.count[i] = cnt[i];
+  if (k.use_scaling) h.scaling = k.scaling;
+  if (k.use_wp) h.wp = k.wp;
+  char *out = (char *)dst;
+  std::memcpy(out, &h, sizeof(h));
+  size_t off = blob_header_bytes();
+  for (int i = 0; i < BL_COUNT; i++) {
+    if (cnt[i]) std::memcpy(out + off, src[i], cnt[i] * kBlobElem[i]);
+    off += align_up(cnt[i] * kBlobElem[i], 16);
+  }
+  return 0;
+}
+
+extern "C" int hevcrecon_syntax_import(hevcrecon_syntax *s, const void *src, int64_t bytes) {
+  if (!s || !src) return 1;
+  auto refuse = [&](const char *why) {
+    s->err = why;
+    return fail(s->ctx, s->err);
+  };
+  if (bytes < (int64_t)blob_header_bytes()) return refuse("packed picture: too short");
+  BlobHeader h;
+  std::memcpy(&h, src, sizeof(h));
+  if (h.magic != kBlobMagic || h.version != kBlobVersion || h.total_bytes != (uint64_t)bytes) return refuse("packed picture: not one (magic, version or length)");
+  size_t total = blob_header_bytes();
+  for (int i = 0; i < BL_COUNT; i++) {
+    if (h.count[i] > ((uint64_t)1 << 28)) return refuse("packed picture: array size out of range");
+    total += align_up((size_t)h.count[i] * kBlobElem[i], 16);
+  }
+  if (total != (size_t)bytes) return refuse("packed picture: array sizes do not add up to its length");
+  if (int rc = hevcrecon_syntax_begin(s)) return rc;  // waits until the GPU is done with the picture the object held
+  if (std::memcmp(&h.seq, &s->si, sizeof(SeqInfo)) != 0) return refuse("packed picture: packed for different sequence parameters");
+  const size_t nctu = (size_t)h.seq.ctus_w * h.seq.ctus_h;
+  for (int l = 0; l < 2; l++)
+    if (h.pp.num_ref[l] < 0 || h.pp.num_ref[l] > HR_MAX_REFS) return refuse("packed picture: bad reference list size");
+  if (h.count[BL_RUNOFF] != nctu + 1 || h.count[BL_SAO] != nctu * 3 || (h.count[BL_CTUI] != 0 && h.count[BL_CTUI] != nctu) || h.count[BL_ICTU] > nctu)
+    return refuse("packed picture: per-CTU tables of the wrong size");
+  PackedPicture &k = s->pk;
+  const char *in = (const char *)src + blob_header_bytes();
+  auto take = [&](int i, auto &vec) {
+    typedef typename std::remove_reference<decltype(vec)>::type V;
+    vec.resize((size_t)h.count[i]);
+    if (h.count[i]) std::memcpy((void *)vec.data(), in, (size_t)h.count[i] * sizeof(typename V::value_type));
+    in += align_up((size_t)h.count[i] * kBlobElem[i], 16);
+  };
+  take(BL_RUNS, k.runs);
+  take(BL_RUNOFF, k.ctu_run_off);
+  take(BL_TU0, k.tu[0]);
+  take(BL_TU1, k.tu[1]);
+  take(BL_TU2, k.tu[2]);
+  take(BL_TU3, k.tu[3]);
+  take(BL_COEFF, k.coeff);
+  take(BL_INTRA, k.intra);
+  take(BL_ICTU, k.ictu);
+  take(BL_ROUNDS, k.rounds);
+  take(BL_WAVE, k.wave_off);
+  take(BL_SAO, k.sao);
+  take(BL_CTUI, k.ctu_info);
+  take(BL_MCT0, k.mc_tile[0]);
+  take(BL_MCT1, k.mc_tile[1]);
+  take(BL_MCT2, k.mc_tile[2]);
+  take(BL_MCB, k.mc_blk);
+  take(BL_SLICES, k.slices);
+  // what the kernels index with has to lie inside the arrays (the exporting packer guarantees it; a blob is foreign input)
+  const size_t n_runs = k.runs.size(), n_intra = k.intra.size(), n_rounds = k.rounds.size(), n_coeff = k.coeff.size();
+  for (size_t a = 0; a + 1 < k.ctu_run_off.size(); a++)
+    if (k.ctu_run_off[a] > k.ctu_run_off[a + 1] || k.ctu_run_off[a + 1] > n_runs) return refuse("packed picture: run table out of range");
+  for (size_t i = 0; i < k.ictu.size(); i++) {
+    const IntraCtu &ic = k.ictu[i];
+    if ((size_t)ic.item_start + ic.n_items > n_intra || (size_t)ic.round_start + ic.n_rounds > n_rounds || ic.n_items > HR_INTRA_MAX_ITEMS ||
+        ic.n_rounds > HR_INTRA_MAX_ROUNDS || ic.cx >= h.seq.ctus_w || ic.cy >= h.seq.ctus_h)
+      return refuse("packed picture: intra CTU table out of range");
+  }
+  for (size_t w = 0; w + 1 < k.wave_off.size(); w++)
+    if (k.wave_off[w] < 0 || k.wave_off[w] > k.wave_off[w + 1] || (size_t)k.wave_off[w + 1] > k.ictu.size()) return refuse("packed picture: intra wave table out of range");
+  for (int t = 0; t < 4; t++)
+    for (size_t i = 0; i < k.tu[t].size(); i++)
+      if (k.tu[t][i].coeff_off >= n_coeff || k.tu[t][i].comp > 2) return refuse("packed picture: transform block out of range");
+  for (int t = 0; t < 3; t++)
+    for (size_t i = 0; i < k.mc_tile[t].size(); i++) {
+      const McTile &m = k.mc_tile[t][i];
+      if (m.x >= h.seq.w || m.y >= h.seq.h || m.ref[0] >= h.pp.num_ref[0] || m.ref[1] >= h.pp.num_ref[1] || (m.ref[0] < 0 && m.ref[1] < 0))
+        return refuse("packed picture: motion region out of range");
+    }
+  for (size_t i = 0; i < k.mc_blk.size(); i++)
+    if (k.mc_blk[i].x >= h.seq.w || k.mc_blk[i].y >= h.seq.h) return refuse("packed picture: motion region out of range");
+  // reference indices as the records hold them (not as the header claims)
+  int max_ref[2] = {-1, -1};
+  bool no_ref = false;
+  for (size_t i = 0; i < n_runs; i++) {
+    const Part4 &r = k.runs[i];
+    if ((size_t)r.pad + r.pad2[0] > 255) return refuse("packed picture: run table out of range");
+    if (r.flags & P4_INTRA) continue;
+    for (int l = 0; l < 2; l++) max_ref[l] = std::max<int>(max_ref[l], r.ref_idx[l]);
+    no_ref = no_ref || (r.ref_idx[0] < 0 && r.ref_idx[1] < 0);
+  }
+  h.max_ref_idx[0] = max_ref[0];
+  h.max_ref_idx[1] = max_ref[1];
+  h.inter_without_ref = no_ref;
+  k.release_work();
+  k.seq = h.seq;
+  k.pp = h.pp;
+  k.coded_coeffs = h.coded_coeffs;
+  k.mc_ref_samples = h.mc_ref_samples;
+  k.n_rec4 = h.n_rec4;
+  k.n_rec4_intra = h.n_rec4_intra;
+  k.max_ref_idx[0] = h.max_ref_idx[0];
+  k.max_ref_idx[1] = h.max_ref_idx[1];
+  k.inter_without_ref = h.inter_without_ref != 0;
+  k.has_bypass = h.has_bypass != 0;
+  k.has_pcm = h.has_pcm != 0;
+  k.use_scaling = h.use_scaling != 0;
+  k.use_wp = h.use_wp != 0;
+  k.scaling = h.scaling;
+  k.wp = h.wp;
+  k.finished = true;
+  k.error.clear();
+  if (!s->ctx) return 0;
+  return stage_packed(s);
 }
 
 // No counterpart in the reference: marks an already packed picture for another trip to the device
@@ -1359,7 +1555,7 @@ extern "C" int hevcrecon_picture_md5_batch(hevcrecon_ctx *c, int n, const int *p
 // far, beside the reconstruction of later pictures; the digests come back into pinned memory and are collected with
 // hevcrecon_picture_md5_poll / _wait.  A picture that a pending ticket still reads is protected: whatever would
 // overwrite it is ordered behind the hash kernel.
-extern "C" int hevcrecon_picture_md5_submit(hevcrecon_ctx *c, int n, const int *pic_ids, int64_t *ticket) {
+static int md5_submit_impl(hevcrecon_ctx *c, int n, const int *pic_ids, int64_t *ticket, bool copies) {
   if (!c || !pic_ids || !ticket) return 1;
   *ticket = -1;
   if (n <= 0 || n > HR_MD5_MAX_PICTURES) return fail(c, "number of pictures to digest out of range");
@@ -1372,25 +1568,34 @@ extern "C" int hevcrecon_picture_md5_submit(hevcrecon_ctx *c, int n, const int *
     // reconstruction kernels leave room
     int least = 0, greatest = 0;
     HIPCHK(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIPCHK(c, hipStreamCreateWithPriority(&c->md5_stream, hipStreamNonBlocking, least));
+    if (const char *e = std::getenv("HEVCRECON_HASH_PRIORITY"))  // experiments: "normal" puts the hash streams on a par with the kernels' stream
+      if (!std::strcmp(e, "normal")) least = 0;
+    for (int i = 0; i < 4; i++) HIPCHK(c, hipStreamCreateWithPriority(&c->md5_streams[i], hipStreamNonBlocking, least));
+    c->md5_stream = c->md5_streams[0];
     HIPCHK(c, hipEventCreateWithFlags(&c->md5_fork, hipEventDisableTiming));
   }
   Md5Slot &m = c->md5_slots[c->md5_next % kMd5Slots];
   if (m.ticket >= 0) return fail(c, "too many picture hashes in flight: collect earlier tickets with hevcrecon_picture_md5_poll or _wait first");
   const size_t desc_bytes = align_up(sizeof(Md5Plane) * 3 * n, 256), dig_bytes = (size_t)48 * n;
-  if (m.cap < (size_t)n || m.snap_pic_bytes != c->pic_bytes) {
-    if (m.dev) hipFree(m.dev);
-    if (m.snap) hipFree(m.snap);
+  if (m.cap < (size_t)n) {
+    if (m.dev) c->retired.push_back(m.dev);  // (freeing waits for the whole device)
     if (m.host) hipHostFree(m.host);
-    m.dev = m.snap = nullptr;
+    m.dev = nullptr;
     m.host = nullptr;
     m.cap = 0;
-    const size_t cap = std::max<size_t>(n, 4);
+    const size_t cap = std::max<size_t>(2 * (size_t)n, 64);
     const size_t bytes = align_up(sizeof(Md5Plane) * 3 * cap, 256) + 48 * cap + 64;
     HIPCHK(c, hipMalloc(&m.dev, bytes));
-    HIPCHK(c, hipMalloc(&m.snap, cap * c->pic_bytes));
     HIPCHK(c, hipHostMalloc((void **)&m.host, bytes));
     m.cap = cap;
+  }
+  if (copies && (m.snap_cap < (size_t)n || m.snap_pic_bytes != c->pic_bytes)) {
+    if (m.snap) c->retired.push_back(m.snap);
+    m.snap = nullptr;
+    m.snap_cap = 0;
+    const size_t cap = std::max<size_t>(n, 4);
+    HIPCHK(c, hipMalloc(&m.snap, cap * c->pic_bytes));
+    m.snap_cap = cap;
     m.snap_pic_bytes = c->pic_bytes;
   }
   if (!m.done) HIPCHK(c, hipEventCreateWithFlags(&m.done, hipEventDisableTiming));
@@ -1399,26 +1604,38 @@ extern "C" int hevcrecon_picture_md5_submit(hevcrecon_ctx *c, int n, const int *
   Md5Plane *d = (Md5Plane *)m.host;  // descriptors, then (after the copy back) the digests, in the slot's pinned buffer
   for (int i = 0; i < n; i++) {
     // the pictures as they are when everything queued so far has run, copied in the kernels' stream
-    char *snap = (char *)m.snap + (size_t)i * c->pic_bytes;
-    HIPCHK(c, hipMemcpyAsync(snap, c->pics[pic_ids[i]].base, c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
+    char *snap = (char *)c->pics[pic_ids[i]].base;
+    if (copies) {
+      snap = (char *)m.snap + (size_t)i * c->pic_bytes;
+      HIPCHK(c, hipMemcpyAsync(snap, c->pics[pic_ids[i]].base, c->pic_bytes, hipMemcpyDeviceToDevice, c->stream));
+    }
     d[i] = Md5Plane{snap + c->plane_off[0], (uint32_t)(s.w * pb), (uint32_t)s.h, (uint32_t)(s.stride_y * pb), 0};
     d[n + 2 * i] = Md5Plane{snap + c->plane_off[1], (uint32_t)(s.cw * pb), (uint32_t)s.ch, (uint32_t)(s.stride_c * pb), 0};
     d[n + 2 * i + 1] = Md5Plane{snap + c->plane_off[2], (uint32_t)(s.cw * pb), (uint32_t)s.ch, (uint32_t)(s.stride_c * pb), 0};
   }
+  hipStream_t hs = c->md5_streams[c->md5_next % 4];
   HIPCHK(c, hipEventRecord(c->md5_fork, c->stream));
-  HIPCHK(c, hipStreamWaitEvent(c->md5_stream, c->md5_fork, 0));
+  HIPCHK(c, hipStreamWaitEvent(hs, c->md5_fork, 0));
   uint8_t *dig_dev = (uint8_t *)m.dev + desc_bytes;
-  HIPCHK(c, hipMemcpyAsync(m.dev, d, sizeof(Md5Plane) * 3 * n, hipMemcpyHostToDevice, c->md5_stream));
-  hr_launch_md5((const Md5Plane *)m.dev, 3 * n, dig_dev, c->md5_stream);
+  HIPCHK(c, hipMemcpyAsync(m.dev, d, sizeof(Md5Plane) * 3 * n, hipMemcpyHostToDevice, hs));
+  hr_launch_md5((const Md5Plane *)m.dev, 3 * n, dig_dev, hs);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(m.host + desc_bytes, dig_dev, dig_bytes, hipMemcpyDeviceToHost, c->md5_stream));
+  HIPCHK(c, hipMemcpyAsync(m.host + desc_bytes, dig_dev, dig_bytes, hipMemcpyDeviceToHost, hs));
   // the error words of the kernels that wrote the pictures (they ran before the copies above) travel with the digests
-  HIPCHK(c, hipMemcpyAsync(m.host + desc_bytes + dig_bytes, c->error_flag_dev, 64, hipMemcpyDeviceToHost, c->md5_stream));
-  HIPCHK(c, hipEventRecord(m.done, c->md5_stream));
+  HIPCHK(c, hipMemcpyAsync(m.host + desc_bytes + dig_bytes, c->error_flag_dev, 64, hipMemcpyDeviceToHost, hs));
+  HIPCHK(c, hipEventRecord(m.done, hs));
   m.ticket = c->md5_next++;
   m.n = n;
   *ticket = m.ticket;
   return 0;
+}
+
+extern "C" int hevcrecon_picture_md5_submit(hevcrecon_ctx *c, int n, const int *pic_ids, int64_t *ticket) {
+  return md5_submit_impl(c, n, pic_ids, ticket, true);
+}
+
+extern "C" int hevcrecon_picture_md5_submit_in_place(hevcrecon_ctx *c, int n, const int *pic_ids, int64_t *ticket) {
+  return md5_submit_impl(c, n, pic_ids, ticket, false);
 }
 
 static int md5_collect(hevcrecon_ctx *c, int64_t ticket, bool block, int *done, uint8_t *digests) {
@@ -1488,7 +1705,8 @@ extern "C" int hevcrecon_picture_upload(hevcrecon_ctx *c, int pic_id, int poc, c
   const size_t pb = c->pel_bytes;
   const size_t ny = (size_t)s.w * s.h * pb, nc = (size_t)s.cw * s.ch * pb;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->md5_stream) HIPCHK(c, hipStreamSynchronize(c->md5_stream));
+  if (c->md5_stream)
+    for (int i = 0; i < 4; i++) HIPCHK(c, hipStreamSynchronize(c->md5_streams[i]));
   if (ensure_staging(c, ny + 2 * nc)) return 1;
   char *h = (char *)c->dl_host;
   const int16_t *src[3] = {y, cb, cr};
@@ -1520,7 +1738,8 @@ extern "C" int hevcrecon_picture_release(hevcrecon_ctx *c, int pic_id) {
   if (pic_id < 0 || pic_id >= (int)c->pics.size()) return 0;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->md5_stream) HIPCHK(c, hipStreamSynchronize(c->md5_stream));
+  if (c->md5_stream)
+    for (int i = 0; i < 4; i++) HIPCHK(c, hipStreamSynchronize(c->md5_streams[i]));
   free_picture(c->pics[pic_id]);
   return 0;
 }
@@ -1531,7 +1750,10 @@ extern "C" int hevcrecon_synchronize(hevcrecon_ctx *c) {
   for (int k = 0; k < kCopyStreams; k++) HIPCHK(c, hipStreamSynchronize(c->copy_stream[k]));
   c->upload_synced = c->upload_no - 1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->md5_stream) HIPCHK(c, hipStreamSynchronize(c->md5_stream));
+  if (c->md5_stream)
+    for (int i = 0; i < 4; i++) HIPCHK(c, hipStreamSynchronize(c->md5_streams[i]));
+  for (size_t i = 0; i < c->retired.size(); i++) hipFree(c->retired[i]);
+  c->retired.clear();
   return check_device_errors(c);
 }
 

@@ -116,6 +116,8 @@ void PackedPicture::begin(const SeqInfo &s) {
   error.clear();
 }
 
+void PackedPicture::release_work() { g_rec_pool.give(rec4); }
+
 bool PackedPicture::set_slices(int n, const hevcrecon_slice_params *sl) {
   if (finished) {
     error = "the slice table must be set between hevcrecon_syntax_begin and hevcrecon_syntax_finish";

@@ -79,6 +79,7 @@ struct PackedPicture {
   int ctu_dep_mask;                   // which of them (IC_DEP_*)
 
   void begin(const SeqInfo &s);
+  void release_work();  // gives the working records back without finishing (the picture arrives packed from elsewhere)
   bool add_ctu(int addr, const hevcrecon_ctu_syntax *ctu);
   bool finish(const hevcrecon_pic_params *pp);
   int64_t algorithmic_bytes() const;

@@ -256,6 +256,47 @@ int hevcrecon_syntax_add_ctu(hevcrecon_syntax *syn, int ctu_addr, const hevcreco
 /* Closes the picture and queues the host-to-device copy of the packed syntax. */
 int hevcrecon_syntax_finish(hevcrecon_syntax *syn, const hevcrecon_pic_params *pp);
 
+/* No counterpart in the reference: a packed picture as one position-independent block of bytes, so that parsing and
+ * reconstruction may live in different processes.  The reference decoder is one thread with global state
+ * (TLibCommon/TComRom.cpp:93-96), so a host that feeds one GPU from many streams runs one decoder process per stream;
+ * a GPU serves only a few processes at a time, and pictures of different streams batch into one set of launches only
+ * inside one context.  A decoder process that never opens the GPU packs into a host-only object
+ * (hevcrecon_syntax_create_detached) and exports; the process that owns the GPU imports and reconstructs
+ * (hevc_amd/csrc/hub.cpp is such a process).
+ * hevcrecon_syntax_export: `syn` is finished; *bytes receives the size; with dst = NULL nothing else happens, else
+ * cap must be at least that.  hevcrecon_syntax_import: stands for begin + add_ctu x N + finish on an object of a
+ * context (or a host-only one) with the same sequence parameters; the block is checked (every index a kernel will
+ * use lies inside its array) and refused with a message otherwise.  Reference picture ids are taken as they are:
+ * exporter and importer agree on them. */
+int hevcrecon_syntax_export(const hevcrecon_syntax *syn, void *dst, int64_t cap, int64_t *bytes);
+int hevcrecon_syntax_import(hevcrecon_syntax *syn, const void *src, int64_t bytes);
+
+/* ---- many decoder processes, one GPU process ------------------------------------------------ */
+
+/* No counterpart in the reference.  The decoder-process side of the hub (hevc_amd/csrc/hub.cpp, started as
+ * `hevcrecon_hub --name NAME --device N`): the decoder packs into a host-only syntax object and, where it would call
+ * hevcrecon_reconstruct and hevcrecon_picture_md5_submit, hands the finished picture to the hub, which reconstructs
+ * the pictures of all connected decoders in common batches and hashes them on the device.  The decoder process itself
+ * never opens the GPU.  A connection has 256 picture ids of its own, hevcrecon_hub_pic_id_base() .. + 255: the
+ * decoder adds the base to every id it names (destinations, and the reference ids in hevcrecon_pic_params).
+ *   hevcrecon_hub_connect      waits for the hub to come up, takes a free slot; all pictures of a connection share `sp`
+ *   hevcrecon_hub_submit       queues the finished picture `syn` for reconstruction into `dst_pic_id` (waits while
+ *                              the connection's request ring is full); requests run in the order they are made
+ *   hevcrecon_hub_copy         queues hevcrecon_picture_copy (concealment of a lost reference)
+ *   hevcrecon_hub_poll / _wait the digests (3 x 16 bytes: Y, Cb, Cr) of the next picture in submission order
+ *   hevcrecon_hub_disconnect   the hub finishes what is queued, then frees the connection's pictures
+ * Failures of the hub on behalf of this connection (a picture it refused) surface from every later call: non-zero,
+ * message in hevcrecon_hub_error(). */
+typedef struct hevcrecon_hub hevcrecon_hub;
+int hevcrecon_hub_connect(const char *name, const hevcrecon_seq_params *sp, hevcrecon_hub **out);
+int hevcrecon_hub_pic_id_base(const hevcrecon_hub *hub);
+int hevcrecon_hub_submit(hevcrecon_hub *hub, const hevcrecon_syntax *syn, int dst_pic_id);
+int hevcrecon_hub_copy(hevcrecon_hub *hub, int dst_pic_id, int src_pic_id, int dst_poc);
+int hevcrecon_hub_poll(hevcrecon_hub *hub, int *got, uint8_t digest[48]);
+int hevcrecon_hub_wait(hevcrecon_hub *hub, uint8_t digest[48]);
+const char *hevcrecon_hub_error(const hevcrecon_hub *hub);
+void hevcrecon_hub_disconnect(hevcrecon_hub *hub);
+
 /* No counterpart in the reference.  Marks an already finished picture for another trip to the device
  * (hevcrecon_syntax_finish marks it once): for hosts that keep packed pictures around, and for measuring the
  * hand-over.  The pictures of a batch that are so marked cross the host link when the batch is submitted: copy
@@ -328,6 +369,9 @@ int hevcrecon_picture_md5_batch(hevcrecon_ctx *ctx, int n, const int *pic_ids, u
  * run: the engine hashes copies of its own (made on the device, in order with the reconstruction kernels), so the
  * caller may reuse the picture ids at once, as a decoder does with its picture buffers. */
 int hevcrecon_picture_md5_submit(hevcrecon_ctx *ctx, int n, const int *pic_ids, int64_t *ticket);
+/* The same without the copies: the caller keeps the pictures as they are until it has collected the ticket (a host
+ * that sets pictures aside itself, with hevcrecon_picture_copy, to hash many of them in one request). */
+int hevcrecon_picture_md5_submit_in_place(hevcrecon_ctx *ctx, int n, const int *pic_ids, int64_t *ticket);
 int hevcrecon_picture_md5_poll(hevcrecon_ctx *ctx, int64_t ticket, int *done, uint8_t *digests);
 int hevcrecon_picture_md5_wait(hevcrecon_ctx *ctx, int64_t ticket, uint8_t *digests);
 

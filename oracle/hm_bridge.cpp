@@ -34,6 +34,10 @@
 //                    engine hashes the pictures on the GPU beside the reconstruction of later ones
 //                    (hevcrecon_picture_md5_submit / _poll) and the status lines, printed in the reference's format
 //                    with its (OK) / (***ERROR***) verdicts and exit code, follow a few pictures later.
+//   "hub"          : as "engine" with HEVCRECON_HASH=device, but this process never opens the GPU: the pictures are packed
+//                    into a host-only syntax object and handed to the hub process named by $HEVCRECON_HUB
+//                    (hevcrecon_hub_submit; hevc_amd/hevcrecon_hub), which reconstructs the pictures of all connected
+//                    decoders in common batches, hashes them and returns the digests.
 //   "pack"         : the reference reconstructs as usual; the CTUs are additionally packed into a host-only
 //                    syntax object exactly as in engine mode (no GPU needed): timing and tests of the host side.
 //   HEVCRECON_TIMING=1 prints one line of JSON to stderr when decoding ends: where the host thread's time went.
@@ -88,7 +92,7 @@ extern bool g_md5_mismatch;  // App/TAppDecoder/decmain.cpp:46: turns into the d
 
 namespace {
 
-enum Mode { MODE_REF, MODE_DUMP, MODE_ENGINE, MODE_PACK };
+enum Mode { MODE_REF, MODE_DUMP, MODE_ENGINE, MODE_PACK, MODE_HUB };
 
 double now() {
   timespec ts;
@@ -138,6 +142,14 @@ struct EngineApi {
   int (*md5_poll)(hevcrecon_ctx *, int64_t, int *, uint8_t *);
   int (*md5_wait)(hevcrecon_ctx *, int64_t, uint8_t *);
   int (*syntax_create_detached)(const hevcrecon_seq_params *, hevcrecon_syntax **);
+  int (*hub_connect)(const char *, const hevcrecon_seq_params *, hevcrecon_hub **);
+  int (*hub_pic_id_base)(const hevcrecon_hub *);
+  int (*hub_submit)(hevcrecon_hub *, const hevcrecon_syntax *, int);
+  int (*hub_copy)(hevcrecon_hub *, int, int, int);
+  int (*hub_poll)(hevcrecon_hub *, int *, uint8_t *);
+  int (*hub_wait)(hevcrecon_hub *, uint8_t *);
+  const char *(*hub_error)(const hevcrecon_hub *);
+  void (*hub_disconnect)(hevcrecon_hub *);
   const char *(*syntax_last_error)(const hevcrecon_syntax *);
   void (*syntax_destroy)(hevcrecon_syntax *);
 };
@@ -145,6 +157,7 @@ struct EngineApi {
 // A status line whose hash verdict is still to come (HEVCRECON_HASH=device)
 struct PendingLine {
   std::string text;          // "POC ... [L1 ...] " as the reference prints it
+  bool hash_field;           // the decoder prints a hash field at all (--SEIpictureDigest)
   bool check;                // an MD5 SEI message came with the picture
   unsigned char want[3][16]; // its digests
   int pic_id;
@@ -160,6 +173,7 @@ struct Bridge {
   std::map<TComPic *, int> pic_ids;
   EngineApi api;
   hevcrecon_ctx *ctx;
+  hevcrecon_hub *hub = NULL;  // MODE_HUB: the connection to the process that owns the GPU
   // Packed pictures in flight: a syntax object is rewritten only when the GPU is done with the picture it held, so
   // the decoder rotates over a few of them and never waits for that.
   enum { kMaxSyntaxObjects = 32 };
@@ -185,13 +199,17 @@ struct Bridge {
       dump = fopen(path ? path : "hevcrecon.syn", "wb");
       if (!dump) { perror("HEVCRECON_DUMP"); exit(EXIT_FAILURE); }
       dump_planes = getenv("HEVCRECON_DUMP_PLANES") && atoi(getenv("HEVCRECON_DUMP_PLANES"));
-    } else if (m && (!strcmp(m, "engine") || !strcmp(m, "pack"))) {
-      mode = !strcmp(m, "engine") ? MODE_ENGINE : MODE_PACK;
+    } else if (m && (!strcmp(m, "engine") || !strcmp(m, "pack") || !strcmp(m, "hub"))) {
+      mode = !strcmp(m, "engine") ? MODE_ENGINE : !strcmp(m, "hub") ? MODE_HUB : MODE_PACK;
       const double t0 = now();
       load_engine();
       tm.engine_init = now() - t0;
       const char *h = getenv("HEVCRECON_HASH");
-      device_hash = mode == MODE_ENGINE && h && !strcmp(h, "device");
+      device_hash = (mode == MODE_ENGINE && h && !strcmp(h, "device")) || mode == MODE_HUB;
+      if (mode == MODE_HUB && writes_output_file()) {
+        fprintf(stderr, "hm_bridge: with a hub the pictures stay on the GPU: no output file can be written (use HEVCRECON_MODE=engine)\n");
+        exit(EXIT_FAILURE);
+      }
       if (device_hash && writes_output_file()) {
         fprintf(stderr, "hm_bridge: HEVCRECON_HASH=device keeps the pictures on the GPU; an output file was asked for, so they are fetched and hashed on the host\n");
         device_hash = false;
@@ -220,7 +238,8 @@ struct Bridge {
   }
 
   void fail(const char *what) {
-    const char *why = (ctx && api.last_error) ? api.last_error(ctx) : (syn && api.syntax_last_error) ? api.syntax_last_error(syn) : "";
+    const char *why = (ctx && api.last_error) ? api.last_error(ctx) : (syn && api.syntax_last_error && *api.syntax_last_error(syn)) ? api.syntax_last_error(syn)
+                      : (hub && api.hub_error) ? api.hub_error(hub) : "";
     fprintf(stderr, "hm_bridge: %s: %s\n", what, why);
     exit(EXIT_FAILURE);
   }
@@ -250,6 +269,14 @@ struct Bridge {
     sym(api.md5_poll, "hevcrecon_picture_md5_poll");
     sym(api.md5_wait, "hevcrecon_picture_md5_wait");
     sym(api.syntax_create_detached, "hevcrecon_syntax_create_detached");
+    sym(api.hub_connect, "hevcrecon_hub_connect");
+    sym(api.hub_pic_id_base, "hevcrecon_hub_pic_id_base");
+    sym(api.hub_submit, "hevcrecon_hub_submit");
+    sym(api.hub_copy, "hevcrecon_hub_copy");
+    sym(api.hub_poll, "hevcrecon_hub_poll");
+    sym(api.hub_wait, "hevcrecon_hub_wait");
+    sym(api.hub_error, "hevcrecon_hub_error");
+    sym(api.hub_disconnect, "hevcrecon_hub_disconnect");
     sym(api.syntax_last_error, "hevcrecon_syntax_last_error");
     sym(api.syntax_destroy, "hevcrecon_syntax_destroy");
     if (mode == MODE_ENGINE) {
@@ -258,10 +285,12 @@ struct Bridge {
     }
   }
 
+  bool on_gpu() const { return mode == MODE_ENGINE || mode == MODE_HUB; }  // the reference's own reconstruction does not run
+  int id_base = 0;  // MODE_HUB: this connection's range of picture ids
   int pic_id(TComPic *p) {
     std::map<TComPic *, int>::iterator it = pic_ids.find(p);
     if (it != pic_ids.end()) return it->second;
-    int id = (int)pic_ids.size();
+    int id = (int)pic_ids.size() + id_base;
     pic_ids[p] = id;
     return id;
   }
@@ -607,6 +636,22 @@ struct Bridge {
       if (syns[0] && memcmp(&sp, &pack_sp, sizeof(sp))) {
         api.syntax_destroy(syns[0]);
         syns[0] = NULL;
+        if (hub) {  // new sequence parameters: a connection of its own (everything of the old one is collected first)
+          pump_hashes(true);
+          api.hub_disconnect(hub);
+          hub = NULL;
+          pic_ids.clear();
+        }
+      }
+      if (mode == MODE_HUB && !hub) {
+        const double t0 = now();
+        const int rc = api.hub_connect(getenv("HEVCRECON_HUB"), &sp, &hub);
+        if (rc) {
+          fprintf(stderr, "hm_bridge: no hub to connect to (hevcrecon_hub_connect: %d)\n", rc);
+          exit(EXIT_FAILURE);
+        }
+        id_base = api.hub_pic_id_base(hub);
+        tm.engine_init += now() - t0;
       }
       pack_sp = sp;
       if (!syns[0] && api.syntax_create_detached(&sp, &syns[0])) fail("hevcrecon_syntax_create_detached");
@@ -686,6 +731,10 @@ struct Bridge {
       if (api.reconstruct(ctx, syn, id)) fail("hevcrecon_reconstruct");  // queued: the GPU works from here on
       pending = pic;
       tm.submit += now() - t0;
+    } else if (mode == MODE_HUB) {
+      t0 = now();
+      if (api.hub_submit(hub, syn, pic_id(pic))) fail("hevcrecon_hub_submit");
+      tm.submit += now() - t0;
     }
     tm.pictures++;
     tm.t_last = now();
@@ -720,7 +769,31 @@ struct Bridge {
   std::deque<int64_t> tickets;       // hash requests in flight, oldest first
   std::deque<int> ticket_sizes;
 
+  // The oldest hash request: its digests, if they are back (or once they are, with `block`), printed behind their lines.
+  bool collect_front(bool block) {
+    const int n = ticket_sizes.front();
+    std::vector<uint8_t> dig((size_t)48 * n);
+    int done = 0;
+    if (block) {
+      if (api.md5_wait(ctx, tickets.front(), &dig[0])) fail("hevcrecon_picture_md5_wait");
+      done = 1;
+    } else if (api.md5_poll(ctx, tickets.front(), &done, &dig[0])) {
+      fail("hevcrecon_picture_md5_poll");
+    }
+    if (!done) return false;
+    while (!lines.empty() && (!lines.front().check || lines.front().ticket == tickets.front())) {
+      unsigned char got[3][16];
+      if (lines.front().check) memcpy(got, &dig[(size_t)48 * lines.front().index], 48);
+      print_line(lines.front(), got);
+      lines.pop_front();
+    }
+    tickets.pop_front();
+    ticket_sizes.pop_front();
+    return true;
+  }
+
   void submit_hashes() {
+    while (tickets.size() >= 32) collect_front(true);  // the engine keeps track of 64 requests
     std::vector<int> ids;
     for (size_t i = 0; i < lines.size(); i++)
       if (lines[i].check && lines[i].ticket < 0 && lines[i].index < 0) ids.push_back(lines[i].pic_id);
@@ -738,6 +811,7 @@ struct Bridge {
     tm.hash_batches++;
   }
   void submit_hashes_reading(int id) {
+    if (mode == MODE_HUB) return;  // the hub hashes every picture right behind its reconstruction
     for (size_t i = 0; i < lines.size(); i++)
       if (lines[i].check && lines[i].ticket < 0 && lines[i].index < 0 && lines[i].pic_id == id) {
         submit_hashes();
@@ -747,6 +821,9 @@ struct Bridge {
   // The verdict of TDecGop.cpp:294-320, printed behind the line it belongs to
   void print_line(const PendingLine &l, unsigned char got[3][16]) {
     fputs(l.text.c_str(), stdout);
+    tm.t_last = now();  // a picture is done when its verdict is
+    tm.wall_last = wall_clock();
+    if (!l.hash_field) return;
     if (!l.check) {
       printf("[:,(unk)] ");
       return;
@@ -764,26 +841,24 @@ struct Bridge {
   // hash request in flight: the batch size follows the decoder's speed by itself.
   void pump_hashes(bool block) {
     const double t0 = now();
-    std::vector<uint8_t> dig;
-    while (!tickets.empty()) {
-      const int n = ticket_sizes.front();
-      dig.resize((size_t)48 * n);
-      int done = 0;
-      if (block) {
-        if (api.md5_wait(ctx, tickets.front(), &dig[0])) fail("hevcrecon_picture_md5_wait");
-        done = 1;
-      } else if (api.md5_poll(ctx, tickets.front(), &done, &dig[0])) {
-        fail("hevcrecon_picture_md5_poll");
-      }
-      if (!done) break;
-      while (!lines.empty() && (!lines.front().check || lines.front().ticket == tickets.front())) {
+    if (mode == MODE_HUB) {  // one digest per picture comes back from the hub, in order
+      while (!lines.empty()) {
         unsigned char got[3][16];
-        if (lines.front().check) memcpy(got, &dig[(size_t)48 * lines.front().index], 48);
+        int have = 0;
+        if (block) {
+          if (api.hub_wait(hub, &got[0][0])) fail("hevcrecon_hub_wait");
+          have = 1;
+        } else if (api.hub_poll(hub, &have, &got[0][0])) {
+          fail("hevcrecon_hub_poll");
+        }
+        if (!have) break;
         print_line(lines.front(), got);
         lines.pop_front();
       }
-      tickets.pop_front();
-      ticket_sizes.pop_front();
+      tm.hash_device += now() - t0;
+      return;
+    }
+    while (!tickets.empty() && collect_front(block)) {
     }
     if (tickets.empty()) {
       while (!lines.empty() && !lines.front().check) {  // lines without a hash to wait for
@@ -810,7 +885,7 @@ struct Bridge {
             "\"startup_s\": %.6f, \"engine_init_s\": %.6f, \"first_to_last_s\": %.6f, \"wall_first\": %.6f, \"wall_last\": %.6f, "
             "\"pack_s\": %.6f, \"finish_s\": %.6f, \"submit_s\": %.6f, \"motion_s\": %.6f, \"wait_s\": %.6f, \"download_s\": %.6f, "
             "\"md5_host_s\": %.6f, \"hash_device_s\": %.6f, \"parse_and_rest_s\": %.6f}\n",
-            mode == MODE_ENGINE ? "engine" : "pack", device_hash ? "device" : "host", tm.pictures, tm.ctus, tm.repacked, tm.hash_batches,
+            mode == MODE_ENGINE ? "engine" : mode == MODE_HUB ? "hub" : "pack", device_hash ? "device" : "host", tm.pictures, tm.ctus, tm.repacked, tm.hash_batches,
             tm.t_first - tm.t_process, tm.engine_init, span, tm.wall_first, tm.wall_last, tm.pack, tm.finish, tm.submit, tm.motion, tm.wait,
             tm.download, tm.md5_host, tm.hash_device, span - ours);
   }
@@ -825,7 +900,7 @@ Bridge &bridge() {
 
 Void TDecCu::decompressCU(TComDataCU *pcCU) {
   Bridge &b = bridge();
-  if (b.mode == MODE_ENGINE) {  // reconstruction is deferred to the engine; the CTU's syntax is handed over now
+  if (b.on_gpu()) {  // reconstruction is deferred to the engine; the CTU's syntax is handed over now
     b.ctu_parsed(pcCU);
     return;
   }
@@ -835,7 +910,7 @@ Void TDecCu::decompressCU(TComDataCU *pcCU) {
 
 Void TComLoopFilter::loopFilterPic(TComPic *pcPic) {
   Bridge &b = bridge();
-  if (b.mode == MODE_ENGINE) {
+  if (b.on_gpu()) {
     b.finish_picture(pcPic);
     return;
   }
@@ -846,14 +921,14 @@ Void TComLoopFilter::loopFilterPic(TComPic *pcPic) {
 }
 
 Void TComSampleAdaptiveOffset::SAOProcess(SAOParam *pcSaoParam) {
-  if (bridge().mode == MODE_ENGINE) return;  // already applied by the engine
+  if (bridge().on_gpu()) return;  // already applied by the engine
   SAOProcess_ref(pcSaoParam);
 }
 
 Void TComSampleAdaptiveOffset::PCMLFDisableProcess(TComPic *pcPic) {
   // the engine has already put lossless coding units back; the reference would copy from per-CU buffers that
   // its skipped reconstruction never filled
-  if (bridge().mode == MODE_ENGINE) return;
+  if (bridge().on_gpu()) return;
   PCMLFDisableProcess_ref(pcPic);
 }
 
@@ -878,7 +953,7 @@ void calcMD5(TComPicYuv &pic, UChar digest[3][16]) {
 // Host-side border padding of reference pictures (TLibCommon/TComSlice.cpp:374-400 calls it for every reference of every
 // slice): only the reference's own motion compensation reads the border, and in engine mode that never runs.
 Void TComPicYuv::extendPicBorder() {
-  if (bridge().mode == MODE_ENGINE) return;
+  if (bridge().on_gpu()) return;
   extendPicBorder_ref();
 }
 
@@ -887,7 +962,7 @@ Void TComPicYuv::extendPicBorder() {
 // picture buffer, device to device (hevcrecon_picture_copy), as soon as the decoder's picture list comes by (below).
 Void TComPicYuv::copyToPic(TComPicYuv *pcPicYuvDst) {
   Bridge &b = bridge();
-  if (b.mode == MODE_ENGINE) {
+  if (b.on_gpu()) {
     b.lost_src_yuv = this;
     b.lost_dst_yuv = pcPicYuvDst;
     if (b.device_hash) return;  // no host copy of any picture exists
@@ -901,7 +976,7 @@ Void TComPicYuv::copyToPic(TComPicYuv *pcPicYuvDst) {
 Int TComSlice::checkThatAllRefPicsAreAvailable(TComList<TComPic *> &rcListPic, TComReferencePictureSet *pReferencePictureSet, Bool printErrors,
                                                Int pocRandomAccess) {
   Bridge &b = bridge();
-  if (b.mode == MODE_ENGINE && b.lost_dst_yuv) {
+  if (b.on_gpu() && b.lost_dst_yuv) {
     TComPic *src = NULL, *dst = NULL;
     for (TComList<TComPic *>::iterator it = rcListPic.begin(); it != rcListPic.end(); ++it) {
       if ((*it)->getPicYuvRec() == b.lost_src_yuv) src = *it;
@@ -913,7 +988,11 @@ Int TComSlice::checkThatAllRefPicsAreAvailable(TComList<TComPic *> &rcListPic, T
       exit(EXIT_FAILURE);
     }
     b.submit_hashes_reading(b.pic_id(dst));
-    if (b.api.picture_copy(b.ctx, b.pic_id(dst), b.pic_id(src), dst->getSlice(0)->getPOC())) b.fail("hevcrecon_picture_copy");
+    if (b.mode == MODE_HUB) {
+      if (b.api.hub_copy(b.hub, b.pic_id(dst), b.pic_id(src), dst->getSlice(0)->getPOC())) b.fail("hevcrecon_hub_copy");
+    } else if (b.api.picture_copy(b.ctx, b.pic_id(dst), b.pic_id(src), dst->getSlice(0)->getPOC())) {
+      b.fail("hevcrecon_picture_copy");
+    }
   }
   return checkThatAllRefPicsAreAvailable_ref(rcListPic, pReferencePictureSet, printErrors, pocRandomAccess);
 }
@@ -922,8 +1001,8 @@ Void TDecGop::filterPicture(TComPic *&rpcPic) {
   Bridge &b = bridge();
   const SEImessages *seis = rpcPic->getSEIs();
   const bool md5_sei = seis && seis->picture_digest && seis->picture_digest->method == SEIDecodedPictureHash::MD5;
-  if (!(b.mode == MODE_ENGINE && b.device_hash && (md5_sei || !(seis && seis->picture_digest) || !m_decodedPictureHashSEIEnabled))) {
-    if (b.mode == MODE_ENGINE && b.device_hash) b.pump_hashes(true);  // keep the lines in order around this picture
+  if (!(b.on_gpu() && b.device_hash && (b.mode == MODE_HUB || md5_sei || !(seis && seis->picture_digest) || !m_decodedPictureHashSEIEnabled))) {
+    if (b.on_gpu() && b.device_hash) b.pump_hashes(true);  // keep the lines in order around this picture
     filterPicture_ref(rpcPic);
     return;
   }
@@ -951,13 +1030,14 @@ Void TDecGop::filterPicture(TComPic *&rpcPic) {
     }
     line.text += "] ";
   }
+  line.hash_field = m_decodedPictureHashSEIEnabled != 0;
   line.check = m_decodedPictureHashSEIEnabled && md5_sei;
   line.pic_id = b.pic_id(rpcPic);
   line.ticket = -1;
   line.index = -1;
   memset(line.want, 0, sizeof(line.want));
   if (line.check) memcpy(line.want, seis->picture_digest->digest, 48);
-  if (!m_decodedPictureHashSEIEnabled) {  // the reference prints no hash field at all then
+  if (!m_decodedPictureHashSEIEnabled && b.mode != MODE_HUB) {  // the reference prints no hash field at all then
     fputs(line.text.c_str(), stdout);
   } else {
     b.lines.push_back(line);
@@ -971,7 +1051,11 @@ Void TDecGop::filterPicture(TComPic *&rpcPic) {
 
 Void TDecTop::deletePicBuffer() {
   Bridge &b = bridge();
-  if (b.mode == MODE_ENGINE && b.device_hash) b.pump_hashes(true);
+  if (b.on_gpu() && b.device_hash) b.pump_hashes(true);
+  if (b.hub) {
+    b.api.hub_disconnect(b.hub);
+    b.hub = NULL;
+  }
   b.report();
   deletePicBuffer_ref();
 }
