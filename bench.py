@@ -44,13 +44,49 @@ def progress(what):
     sys.stderr.flush()
 
 
-def clone_for_stream(pic, s):
+def clone_for_stream(pic, s, ref_index=None):
+    """The picture as stream s sees it: its reference ids moved into the stream's range.  With `ref_index` (decoding
+    index of every reference, see reference_indices) pictures are named by their decoding index instead of by the
+    decoder's picture buffer: every picture of a pass then has an id of its own, and pictures can be reconstructed in
+    another order than they were decoded in without one overwriting a buffer that another still reads."""
     p = copy.copy(pic)
     p.pic_params = type(pic.pic_params).from_buffer_copy(pic.pic_params)
     for l in range(2):
         for r in range(p.pic_params.num_ref[l]):
-            p.pic_params.ref_pic_id[l][r] = pic.pic_params.ref_pic_id[l][r] + s * ID_STRIDE
+            p.pic_params.ref_pic_id[l][r] = (pic.pic_params.ref_pic_id[l][r] if ref_index is None else ref_index[l][r]) + s * ID_STRIDE
     return p
+
+
+def reference_indices(seq):
+    """Per picture (decoding order) and list, the decoding index of every reference: the latest earlier picture that was
+    decoded into the buffer the list names."""
+    last, out = {}, []
+    for t, pic in enumerate(seq.pictures):
+        pp = pic.pic_params
+        out.append([[last[pp.ref_pic_id[l][r]] for r in range(pp.num_ref[l])] for l in range(2)])
+        last[pic.pic_id] = t
+    return out
+
+
+def level_schedule(seq, window=8):
+    """Batches of mutually independent pictures of ONE stream.  Parsing never reads samples, so a decoder can parse a
+    group of pictures ahead and hand its pictures over by dependency level instead of one by one: of the random-access
+    hierarchy's eight pictures per group (decoded 8 4 2 1 3 6 5 7) first 8, then 4, then 2 and 6, then 1 3 5 7, which
+    refer to nothing inside their batch (TLibCommon/TComSlice.cpp:450-465 builds the lists; SURVEY of the dependencies
+    in the cfg: cfg/encoder_randomaccess_main.cfg:29-36).  The first picture stands alone; after it, windows of `window`
+    pictures in decoding order, inside a window a picture's level is one more than the highest level among its
+    references in the window."""
+    refs = reference_indices(seq)
+    n = len(seq.pictures)
+    batches = [[0]]
+    for w0 in range(1, n, window):
+        idx = list(range(w0, min(n, w0 + window)))
+        level = {}
+        for t in idx:
+            level[t] = 1 + max([level[r] for l in range(2) for r in refs[t][l] if r in level], default=-1)
+        for lv in range(max(level.values()) + 1):
+            batches.append([t for t in idx if level[t] == lv])
+    return batches
 
 
 def kernel_bytes(sp, st, sao):
@@ -318,10 +354,22 @@ class Workload:
     picture per step.  Stream s starts at step off[s] and then plays its 60 pictures over and over (picture 0 is an
     intra picture, so every pass is a correct decode and every picture can be checked at any time)."""
 
-    def __init__(self, seqs, S, C, device, upload_ring, stagger):
+    def __init__(self, seqs, S, C, device, upload_ring, stagger, by_level=False):
         self.seqs, self.S, self.C = seqs, S, C
         self.sp = seqs[0].seq_params
         self.npic = len(seqs[0].pictures)
+        # what a step reconstructs of every stream: picture t (decoding order), or, by dependency level, a batch of
+        # pictures that do not refer to each other (the same for every clip: they share the encoder's configuration)
+        self.by_level = by_level
+        self.schedule = [[t] for t in range(self.npic)]
+        self.ref_index = [None] * len(seqs)
+        if by_level:
+            self.schedule = level_schedule(seqs[0])
+            for seq in seqs[1:]:
+                if level_schedule(seq) != self.schedule:
+                    raise SystemExit("bench: the clips differ in their reference structure")
+            self.ref_index = [reference_indices(seq) for seq in seqs]
+        self.period = len(self.schedule)  # steps per pass
         nseeds = len(seqs)
         self.seed_of = [s % nseeds for s in range(S)]
         self.ctx_of = [(s // nseeds) % C if S >= nseeds * C else s % C for s in range(S)]
@@ -341,7 +389,7 @@ class Workload:
                 pic.ctu_structs()
                 for s in range(S):
                     if self.seed_of[s] == k:
-                        y = self.engs[self.ctx_of[s]].new_syntax().pack(clone_for_stream(pic, s))
+                        y = self.engs[self.ctx_of[s]].new_syntax().pack(clone_for_stream(pic, s, self.ref_index[k][t] if by_level else None))
                         self.syns[t][s] = y
                         self.pack_s += y.pack_seconds
                         self.pack_n += 1
@@ -355,7 +403,7 @@ class Workload:
     def set_offsets(self, stagger):
         """Grouped (default): the streams of a context share their position, the contexts are 60 / C pictures apart.
         Staggered: every stream of a context at its own position."""
-        npic = self.npic
+        npic = self.period
         self.off = [0] * self.S
         for c, g in enumerate(self.groups):
             for j, s in enumerate(g):
@@ -364,18 +412,39 @@ class Workload:
         self._prepared = {}
 
     def members(self, c, g):
-        return [(s, (g - self.off[s]) % self.npic) for s in self.groups[c] if g >= self.off[s]]
+        return [(s, t) for s in self.groups[c] if g >= self.off[s] for t in self.schedule[(g - self.off[s]) % self.period]]
 
     def prepared(self, c, g):
-        """Argument arrays of context c's batch at step g (steps past the ramp-up repeat with period 60)."""
-        key = (c, g if g < self.max_off else self.max_off + (g - self.max_off) % self.npic)
+        """Argument arrays of context c's batch at step g (steps past the ramp-up repeat with the period of a pass)."""
+        key = (c, g if g < self.max_off else self.max_off + (g - self.max_off) % self.period)
         if key not in self._prepared:
             m = self.members(c, g)
             self._prepared[key] = self.engs[c].prepare_batch([self.syns[t][s] for s, t in m], [self.pic_id(s, t) for s, t in m]) if m else None
         return self._prepared[key]
 
     def pic_id(self, s, t):
-        return self.seqs[self.seed_of[s]].pictures[t].pic_id + s * ID_STRIDE
+        return (t if self.by_level else self.seqs[self.seed_of[s]].pictures[t].pic_id) + s * ID_STRIDE
+
+    def passes(self, first_step, n):
+        """n passes of every stream over its pictures, from step first_step on; returns the next step."""
+        for g in range(first_step, first_step + n * self.period):
+            self.step(g)
+        return first_step + n * self.period
+
+    def ramp_up(self):
+        """Streams start one after the other; returns the first step at which all of them run."""
+        for g in range(self.max_off):
+            self.step(g)
+        return self.max_off
+
+    def timed_passes(self, n=2, warm=1):
+        """Frames per second over n passes (after the ramp-up and `warm` passes)."""
+        g = self.passes(self.ramp_up(), warm)
+        self.synchronize()
+        t0 = time.perf_counter()
+        self.passes(g, n)
+        self.synchronize()
+        return n * self.npic * self.S / (time.perf_counter() - t0)
 
     def step(self, g, upload=False):
         for c in range(self.C):
@@ -409,6 +478,9 @@ def main():
                     help="engine contexts (HIP streams) the streams of this GPU are spread over; with several, one context's "
                          "latency-bound intra kernel runs beside the others' throughput-bound kernels")
     ap.add_argument("--seeds", type=int, default=8, help="different clips among the streams (the fixture and its _s1 .. _s7 variants)")
+    ap.add_argument("--group-by-level", action="store_true",
+                    help="a step reconstructs, of every stream, a batch of pictures that do not refer to each other (dependency levels of "
+                         "the stream's group of pictures) instead of one picture in decoding order")
     ap.add_argument("--stagger", action="store_true", help="every stream at its own decoding position (default: one position per context)")
     ap.add_argument("--fixture", default="randomaccess_main_1920x1080")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -494,8 +566,8 @@ def main():
     sp = seqs[0].seq_params
     S = args.streams
     C = max(1, min(args.contexts, S))
-    W = Workload(seqs, S, C, local_rank, args.upload_ring, args.stagger)
-    npic, engs, groups = W.npic, W.engs, W.groups
+    W = Workload(seqs, S, C, local_rank, args.upload_ring, args.stagger, args.group_by_level)
+    npic, engs, groups, period = W.npic, W.engs, W.groups, W.period
     W.synchronize()
     alg_bytes_stream = [sum(W.syns[t][s].algorithmic_bytes() for t in range(npic)) for s in range(S)]
 
@@ -507,21 +579,12 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    def run_passes(first_step, n_pass):
-        for gg in range(first_step, first_step + n_pass * npic):
-            W.step(gg)
-        return first_step + n_pass * npic
-
     # ramp-up (streams start one after the other) and warm-up passes, then the timed passes
     progress("warm-up and timed passes")
-    g = 0
-    while g < W.max_off:
-        W.step(g)
-        g += 1
-    g = run_passes(g, max(1, args.warmup))
+    g = W.passes(W.ramp_up(), max(1, args.warmup))
     sync()
     t0 = time.perf_counter()
-    g = run_passes(g, args.steps)
+    g = W.passes(g, args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, dist, device=red_dev)
@@ -532,7 +595,7 @@ def main():
     progress("timed passes done: %.1f frames/s; checking every picture" % (npic * S * args.steps / elapsed))
     bd = [sp.bit_depth_luma, sp.bit_depth_chroma, sp.bit_depth_chroma]
     checked = 0
-    for gg in range(g, g + npic):
+    for gg in range(g, g + period):
         W.step(gg)
         for c in range(C):
             m = W.members(c, gg)
@@ -547,14 +610,14 @@ def main():
                     if got != w:
                         raise SystemExit("bench: stream %d picture %d differs from the reference decoder's MD5 (device hash)" % (s, t))
                     checked += 1
-    g += npic
+    g += period
 
     # ---- per-kernel time with HIP events on the engine's stream (one extra, untimed pass of context 0 alone: with
     # several contexts the kernels of different contexts overlap, so their times are taken without the others) ----
     progress("per-kernel times")
     eng = engs[0]
     eng.profile_enable(True)
-    for gg in range(g, g + npic):
+    for gg in range(g, g + period):
         p = W.prepared(0, gg)
         if p is not None:
             eng.reconstruct_prepared(p)
@@ -605,11 +668,13 @@ def main():
         "dtype": "u8" if sp.bit_depth_luma <= 8 else "u16",
         "data": "synthetic",
         "config": {"workload": "%dx%d %d-frame streams (encoder_%s.cfg) of %d different clips, %d independent streams per GPU "
-                               "over %d engine contexts, %s, stream-sharded, no collectives"
+                               "over %d engine contexts, %s%s, stream-sharded, no collectives"
                                % (sp.width, sp.height, npic, args.fixture.rsplit("_", 1)[0], len(seqs), S, C,
                                   "every stream at its own decoding position" if args.stagger else
-                                  "the streams of a context at one decoding position, the contexts %d pictures apart" % (npic // C)),
-                   "streams_per_gpu": S, "contexts_per_gpu": C, "frames_per_stream": npic, "clips": len(seqs), "staggered": bool(args.stagger),
+                                  "the streams of a context at one decoding position, the contexts %d pictures apart" % (npic // C),
+                                  ", pictures of a stream that do not refer to each other in one batch (%d batches per %d pictures)" % (period, npic)
+                                  if args.group_by_level else ""),
+                   "streams_per_gpu": S, "contexts_per_gpu": C, "frames_per_stream": npic, "clips": len(seqs), "staggered": bool(args.stagger), "group_by_level": bool(args.group_by_level),
                    "upload_ring": bool(args.upload_ring), "md5_exact": True, "md5_checked_pictures": checked if not args.check_two_streams_only else 2 * npic},
         "recon_alg_gbps": round(sum(alg_bytes_stream) * args.steps / elapsed / 1e9, 2),
         "recon_alg_gbps_gpu_time": round(sum(alg_bytes_stream[s] for s in groups[0]) / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None,
@@ -618,7 +683,7 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                      "alg_bytes_per_launch": int(kb[dom] / max(dom_launches, 1)),
                      "launches_per_step": int(dom_launches), "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 3),
-                     "pictures_per_launch": S_prof, "timed_in": "a pass of one context alone (HIP events on its stream)"},
+                     "pictures_per_launch": round(S_prof * npic / period, 1), "timed_in": "a pass of one context alone (HIP events on its stream)"},
         "kernels": kernels,
         "packer_us_per_picture": round(W.pack_s / max(W.pack_n, 1) * 1e6, 1),
     }
@@ -633,113 +698,48 @@ def main():
             up_bytes = sum(W.syns[t][s].stats()[29] for t in range(npic) for s in range(S))
             sync()
             t0 = time.perf_counter()
-            for gg in range(g, g + 2 * npic):
+            for gg in range(g, g + 2 * period):
                 W.step(gg, upload=True)
             sync()
             t_both = (time.perf_counter() - t0) / 2
-            g += 2 * npic
+            g += 2 * period
             result["handover"] = {"bytes_per_frame": up_bytes // (npic * S), "with_reconstruction_frames_per_s": round(npic * S / t_both, 1),
                                   "link_gbps": round(up_bytes / t_both / 1e9, 2)}
         # ---- fewer streams: 1 and 8 streams of context 0 alone (what one decoder process, or 64 streams over 8 GPUs
         # = 8 per GPU, get out of the device), and all streams each at its own position ----
         progress("side measurements: fewer streams")
         side = {}
-        for n_small in (1, 8):
-            if n_small <= len(groups[0]) and "fewer" in extras:
-                sub = groups[0][:n_small]
-                preps = [engs[0].prepare_batch([W.syns[t][s] for s in sub], [W.pic_id(s, t) for s in sub]) for t in range(npic)]
-                for p in preps:
-                    engs[0].reconstruct_prepared(p)
-                engs[0].synchronize()
-                t0 = time.perf_counter()
-                for _ in range(2):
-                    for p in preps:
-                        engs[0].reconstruct_prepared(p)
-                engs[0].synchronize()
-                side["streams_%d_frames_per_s" % n_small] = round(2 * npic * n_small / (time.perf_counter() - t0), 1)
-        if C >= 2 and len(groups[0]) >= 4 and len(groups[1]) >= 4 and "fewer" in extras:
-            # the same 8 streams as two contexts of 4, half a pass apart: one context's launch latency and intra chain
-            # run beside the other's kernels
-            subs = [groups[0][:4], groups[1][:4]]
-            preps = [[engs[c].prepare_batch([W.syns[t][s] for s in subs[c]], [W.pic_id(s, t) for s in subs[c]]) for t in range(npic)] for c in range(2)]
-            for rep in range(3):
-                if rep == 1:
-                    sync()
-                    t0 = time.perf_counter()
-                for t in range(npic):
-                    engs[0].reconstruct_prepared(preps[0][t])
-                    engs[1].reconstruct_prepared(preps[1][(t + npic // 2) % npic])
-            sync()
-            side["streams_8_over_two_contexts_frames_per_s"] = round(2 * npic * 8 / (time.perf_counter() - t0), 1)
-        if len(groups[0]) >= 2 and "fewer" in extras:
-            # 8 streams over four fresh contexts of 2 (four is the number of hardware queues a process gets): what 64
-            # streams over 8 GPUs can get out of each device
-            n_ctx, n_str = 4, 8
-            engs4 = [engine.Engine(sp, device=local_rank) for _ in range(n_ctx)]
-            syn4 = [[None] * n_str for _ in range(npic)]
-            for k, seq in enumerate(seqs):
-                for t, pic in enumerate(seq.pictures):
-                    for s4 in range(n_str):
-                        if s4 % len(seqs) == k:
-                            syn4[t][s4] = engs4[s4 % n_ctx].new_syntax().pack(clone_for_stream(pic, s4))
-                    pic.drop_ctypes()
-            preps = [[engs4[c].prepare_batch([syn4[t][s4] for s4 in range(c, n_str, n_ctx)],
-                                             [seqs[s4 % len(seqs)].pictures[t].pic_id + s4 * ID_STRIDE for s4 in range(c, n_str, n_ctx)])
-                      for t in range(npic)] for c in range(n_ctx)]
-            # the contexts start a quarter of a pass apart; once each has played a whole pass (every picture is on the
-            # device then) two passes are timed
-            def play(t_from, t_to):
-                for t in range(t_from, t_to):
-                    for c in range(n_ctx):
-                        tt = t - c * npic // n_ctx
-                        if tt >= 0:
-                            engs4[c].reconstruct_prepared(preps[c][tt % npic])
-            t_start = (n_ctx - 1) * npic // n_ctx + npic
-            play(0, t_start)
-            for e in engs4:
-                e.synchronize()
-            t0 = time.perf_counter()
-            play(t_start, t_start + 2 * npic)
-            for e in engs4:
-                e.synchronize()
-            side["streams_8_over_four_contexts_frames_per_s"] = round(2 * npic * n_str / (time.perf_counter() - t0), 1)
-            for row in syn4:
-                for y in row:
-                    if y is not None:
-                        y.close()
-            for e in engs4:
-                e.close()
+        if "fewer" in extras:
+            # What a few streams get out of the device (one decoder process; 64 streams over 8 GPUs = 8 per GPU): in
+            # decoding order, one picture of every stream per batch; and by dependency level, the pictures of a stream
+            # that do not refer to each other in one batch (level_schedule).  8 streams also over two and four contexts
+            # (one context's launch latency and intra chain beside the others' kernels).
+            def few(n_str, n_ctx, by_level):
+                Wf = Workload(seqs, n_str, n_ctx, local_rank, args.upload_ring, False, by_level)
+                fps = Wf.timed_passes(2)
+                Wf.close()
+                return round(fps, 1)
+
+            for n_small in (1, 8):
+                if n_small <= S:
+                    side["streams_%d_frames_per_s" % n_small] = few(n_small, 1, False)
+                    side["streams_%d_by_level_frames_per_s" % n_small] = few(n_small, 1, True)
+            if S >= 8:
+                side["streams_8_over_two_contexts_frames_per_s"] = few(8, 2, False)
+                side["streams_8_over_four_contexts_frames_per_s"] = few(8, 4, False)
+                side["streams_8_by_level_over_two_contexts_frames_per_s"] = few(8, 2, True)
+            side["batches_per_pass_by_level"] = len(level_schedule(seqs[0]))
         progress("side measurements: every stream at its own position")
         if not args.stagger and S >= 2 * C and "stagger" in extras:
             W.set_offsets(True)
-            gg = 0
-            while gg < W.max_off:
-                W.step(gg)
-                gg += 1
-            gg = run_passes(gg, 1)
-            sync()
-            t0 = time.perf_counter()
-            gg = run_passes(gg, 2)
-            sync()
-            side["every_stream_at_its_own_position_frames_per_s"] = round(2 * npic * S / (time.perf_counter() - t0), 1)
+            side["every_stream_at_its_own_position_frames_per_s"] = round(W.timed_passes(2), 1)
             if C != 4 and S >= 8:
                 # the same over four contexts: with an I picture in every batch the intra kernel's dependency chains are
                 # what a batch waits for, and four batches in flight hide more of them than two
-                W4 = Workload(seqs, S, 4, local_rank, False, True)
-                gg = 0
-                while gg < W4.max_off:
-                    W4.step(gg)
-                    gg += 1
-                for _ in range(npic):
-                    W4.step(gg)
-                    gg += 1
-                W4.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(2 * npic):
-                    W4.step(gg)
-                    gg += 1
-                W4.synchronize()
-                side["every_stream_at_its_own_position_over_four_contexts_frames_per_s"] = round(2 * npic * S / (time.perf_counter() - t0), 1)
+                W.close()
+                W = None
+                W4 = Workload(seqs, S, 4, local_rank, args.upload_ring, True, args.group_by_level)
+                side["every_stream_at_its_own_position_over_four_contexts_frames_per_s"] = round(W4.timed_passes(2), 1)
                 W4.close()
         result["fewer_streams"] = side
         if e2e is not None:
@@ -751,7 +751,8 @@ def main():
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(result))
-    W.close()
+    if W is not None:
+        W.close()
     if dist is not None:
         dist.destroy_process_group()
 

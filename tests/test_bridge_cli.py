@@ -28,8 +28,10 @@ def emu_path():
     return EMU
 
 
-def run_bridge(bitstream, lib, mode="engine", hash_mode=None, out=None, timing=True):
+def run_bridge(bitstream, lib, mode="engine", hash_mode=None, out=None, timing=True, hub=None):
     env = dict(os.environ, HEVCRECON_MODE=mode, HEVCRECON_LIB=lib)
+    if hub:
+        env["HEVCRECON_HUB"] = hub
     if hash_mode:
         env["HEVCRECON_HASH"] = hash_mode
     if timing:
@@ -114,3 +116,53 @@ def lost_picture_case(lib, tmp_path):
 @needs_bridge
 def test_lost_reference_is_concealed_in_the_engine_too(emu_path, tmp_path):
     lost_picture_case(emu_path, tmp_path)
+
+
+def decoders_behind_a_hub(hub_binary, lib, streams):
+    """Several decoder processes that never open the GPU, one hub process that does (hevc_amd/csrc/hub.cpp): every
+    decoder packs on its own, hands its pictures over through shared memory, gets the digests back and prints the
+    reference's status lines with them.  Streams with different sequence parameters get contexts of their own in the
+    hub; pictures of streams that share them share batches."""
+    import threading
+
+    name = "test_%d" % os.getpid()
+    hub = subprocess.Popen([hub_binary, "--name", name, "--idle-exit", "1"], stderr=subprocess.PIPE)
+    results = [None] * len(streams)
+
+    def one(k):
+        results[k] = run_bridge(os.path.join(GOLDEN, streams[k] + ".bin"), lib, mode="hub", hub=name)
+
+    threads = [threading.Thread(target=one, args=(k,)) for k in range(len(streams))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    try:
+        hub_err = hub.communicate(timeout=60)[1].decode("latin1")
+    except subprocess.TimeoutExpired:
+        hub.kill()
+        raise AssertionError("the hub did not leave after its last client")
+    assert hub.returncode == 0, hub_err
+    want = json.load(open(os.path.join(GOLDEN, "hm_md5.json")))
+    total = 0
+    for stream, (rc, out, err) in zip(streams, results):
+        assert rc == 0, (stream, out[-500:], err[-500:])
+        assert status_lines(out) == want[stream] and "ERROR" not in out, stream
+        t = timing_of(err)
+        assert t["mode"] == "hub" and t["repacked"] == 0 and t["pictures"] == len(want[stream])
+        total += len(want[stream])
+    m = re.search(r"(\d+) pictures in (\d+) batches", hub_err)
+    assert m and int(m.group(1)) == total, hub_err
+    return int(m.group(2)), total
+
+
+@needs_bridge
+def test_decoders_behind_a_hub(emu_path):
+    hub = os.path.join(os.path.dirname(emu_path), "hevcrecon_hub_emu")
+    decoders_behind_a_hub(hub, emu_path, ["randomaccess_main_240", "lowdelay_P_main_240", "randomaccess_he10_240"])
+
+
+@needs_bridge
+def test_a_decoder_without_a_hub_says_so(emu_path):
+    rc, out, err = run_bridge(os.path.join(GOLDEN, "intra_main_240.bin"), emu_path, mode="hub", hub="nobody_%d" % os.getpid())
+    assert rc != 0 and "no hub" in err

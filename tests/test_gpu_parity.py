@@ -182,6 +182,47 @@ def test_drop_in_with_the_device_hash(bits, npics):
     assert t["hash"] == "device" and t["repacked"] == 0 and t["download_s"] == 0 and t["md5_host_s"] == 0 and t["pictures"] == npics
 
 
+def test_decoders_behind_a_hub_on_the_gpu():
+    """Six decoder processes (four 1080p streams of two kinds, two small ones) behind hevc_amd/hevcrecon_hub: the only
+    process that opens the GPU.  Every status line carries the unmodified reference decoder's digests, and pictures of
+    different streams shared batches."""
+    from test_bridge_cli import BRIDGE, decoders_behind_a_hub
+    from conftest import ROOT
+    from hevc_amd import abi
+
+    hub = os.path.join(ROOT, "hevc_amd", "hevcrecon_hub")
+    if not (os.path.exists(BRIDGE) and os.path.exists(hub)):
+        pytest.skip("bridge decoder or hub not built")
+    batches, pictures = decoders_behind_a_hub(hub, abi.LIB_PATH, ["randomaccess_main_1080", "randomaccess_main_1080", "randomaccess_main_1080",
+                                                                  "randomaccess_he10_1080", "wpb_240", "slices_tiles_nolf_240"])
+    assert batches < pictures
+
+
+def test_import_of_an_exported_picture_reconstructs_the_same():
+    """hevcrecon_syntax_export on a host-only object, hevcrecon_syntax_import on an object of a context: the pictures of a
+    stream reconstructed from imported blocks carry the reference decoder's digests."""
+    import ctypes as C
+    from hevc_amd import abi
+
+    seq = load_golden("randomaccess_main_416x240")
+    lib = abi.load_library()
+    eng = engine.Engine(seq.seq_params)
+    host = engine.detached_syntax(seq.seq_params)
+    syn = eng.new_syntax()
+    for pic in seq.pictures:
+        host.pack(pic)
+        n = C.c_int64(0)
+        assert lib.hevcrecon_syntax_export(host.h, None, 0, C.byref(n)) == 0
+        blob = (C.c_uint8 * n.value)()
+        assert lib.hevcrecon_syntax_export(host.h, blob, n.value, C.byref(n)) == 0
+        assert lib.hevcrecon_syntax_import(syn.h, blob, n.value) == 0, lib.hevcrecon_last_error(eng.ctx)
+        eng.reconstruct(syn, pic.pic_id)
+        assert eng.md5([pic.pic_id]) == [pic.stage_md5[2]], pic.poc
+    host.close()
+    syn.close()
+    eng.close()
+
+
 def test_lost_reference_is_concealed_on_the_gpu(tmp_path):
     from test_bridge_cli import BRIDGE, lost_picture_case
     from hevc_amd import abi
@@ -340,6 +381,16 @@ def test_bench_contract_single_gpu():
         assert e2e["concurrent"]["processes"] == 2 and e2e["concurrent"]["frames"] == 2 * 8 * 60 and d["packer_us_per_picture_c"] > 0
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and d["config"]["md5_exact"]
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+@pytest.mark.gpu
+def test_bench_batches_by_dependency_level():
+    """`--group-by-level`: the pictures of a stream that do not refer to each other are reconstructed in one batch, in
+    another order than they were decoded in and under picture ids of their own; the benchmark's parity pass checks the
+    digest of every picture of every stream against the reference decoder's."""
+    d = _bench_line(["bench.py", "--steps", "1", "--warmup", "1", "--streams", "3", "--group-by-level", "--no-cpu-baseline", "--no-extras"])
+    assert d["config"]["group_by_level"] and d["config"]["md5_exact"] and d["config"]["md5_checked_pictures"] == 3 * 60
+    assert d["value"] > 0 and d["roofline"]["pictures_per_launch"] > 2
 
 
 @pytest.mark.gpu

@@ -204,3 +204,41 @@ def test_slice_table_is_checked():
     assert lib.hevcrecon_syntax_begin(syn.h) == 0
     assert lib.hevcrecon_syntax_set_slices(syn.h, 0, None) == 0
     syn.close()
+
+
+@pytest.mark.parametrize("stream", ["randomaccess_main", "intra_main", "slices_tiles_nolf", "wpb", "scalinglist", "pcm"])
+def test_packed_picture_survives_export_and_import(stream):
+    """hevcrecon_syntax_export / _import: a finished picture as one block of bytes, read back into another (host-only)
+    object: same statistics, same algorithmic bytes, and the same block when exported again.  Damaged blocks are
+    refused with a message."""
+    seq = load_golden(stream + "_416x240", 2)
+    lib = abi.load_library()
+    for pic in seq.pictures:
+        a = engine.detached_syntax(seq.seq_params).pack(pic)
+        n = C.c_int64(0)
+        assert lib.hevcrecon_syntax_export(a.h, None, 0, C.byref(n)) == 0 and n.value > 0
+        blob = (C.c_uint8 * n.value)()
+        assert lib.hevcrecon_syntax_export(a.h, blob, n.value - 1, C.byref(n)) != 0  # too little room
+        assert lib.hevcrecon_syntax_export(a.h, blob, n.value, C.byref(n)) == 0
+        b = engine.detached_syntax(seq.seq_params)
+        assert lib.hevcrecon_syntax_import(b.h, blob, n.value) == 0, lib.hevcrecon_syntax_last_error(b.h)
+        sa, sb = a.stats(), b.stats()
+        sa[12] = sb[12] = 0  # a packing statistic that does not travel (dependency levels per CTU, summed)
+        assert sb == sa and b.algorithmic_bytes() == a.algorithmic_bytes()
+        again = (C.c_uint8 * n.value)()
+        m = C.c_int64(0)
+        assert lib.hevcrecon_syntax_export(b.h, again, n.value, C.byref(m)) == 0 and m.value == n.value
+        assert bytes(again) == bytes(blob)
+        # damage: wrong length, a count that does not add up, an index beyond its array
+        assert lib.hevcrecon_syntax_import(b.h, blob, n.value - 16) != 0
+        bad = (C.c_uint8 * n.value).from_buffer_copy(blob)
+        bad[0] ^= 0xFF
+        assert lib.hevcrecon_syntax_import(b.h, bad, n.value) != 0
+        assert "packed picture" in lib.hevcrecon_syntax_last_error(b.h).decode()
+        other = abi.SeqParams.from_buffer_copy(seq.seq_params)
+        other.width += 64
+        c = engine.detached_syntax(other)
+        assert lib.hevcrecon_syntax_import(c.h, blob, n.value) != 0
+        assert "sequence parameters" in lib.hevcrecon_syntax_last_error(c.h).decode()
+        for y in (a, b, c):
+            y.close()
