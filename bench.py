@@ -631,26 +631,50 @@ def main():
             one = kernel_bytes(sp, W.stats[k][t], bool(pic.pic_params.sao_luma or pic.pic_params.sao_chroma))
             for name in KERNELS:
                 kb[name] += one[name]
+    # hardware-counter figures of this very configuration, when they have been collected and committed
+    # (tools/pmc_passes.sh -> tools/pmc_traffic.py -> profiles/hbm_traffic.json): HBM bytes and vector-ALU occupancy per launch
+    counters = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            for cfg in json.load(f).get("configs", []):
+                if cfg.get("streams") == S_prof and cfg.get("fixture") == args.fixture and cfg.get("clips", 1) == len(seqs):
+                    counters = cfg.get("kernels", {})
+    except (OSError, ValueError):
+        pass
     kernels = {}
     for name, nbytes in kb.items():
         ms, launches = prof[name]
         kernels[name] = {"ms_per_step": round(ms, 4), "launches": int(launches),
                          "alg_gbps": round(nbytes / (ms * 1e-3) / 1e9, 2) if ms > 0 else None}
+        # what the kernel really moved to and from HBM (the algorithmic figure also counts samples a filter skips and
+        # bytes that never leave the caches)
+        if name in counters and ms > 0:
+            kernels[name]["hbm_traffic_gbps"] = round(counters[name]["bytes_per_launch"] * launches / (ms * 1e-3) / 1e9, 2)
     dom = max(kb, key=lambda k: prof[k][0])
     dom_ms, dom_launches = prof[dom]
     achieved = kb[dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     gpu_ms = sum(prof[k][0] for k in kb)
 
-    # HBM traffic of the dominant kernel: not measurable from inside the process; taken from the committed PMC
-    # passes (tools/pmc_passes.sh -> tools/pmc_traffic.py) when they were collected on this very configuration
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            tj = json.load(f)
-        if tj.get("streams") == S_prof and tj.get("fixture") == args.fixture and tj.get("clips", 1) == len(seqs) and dom in tj.get("kernels", {}):
-            traffic = tj["kernels"][dom]["bytes_per_launch"]
-    except (OSError, ValueError):
-        pass
+    # HBM traffic and vector-ALU occupancy of the dominant kernel: hardware counters, not measurable from inside the
+    # process; taken from the committed PMC passes (tools/pmc_passes.sh -> tools/pmc_traffic.py) when they were
+    # collected on this very configuration.  The kernel is called bound by whichever of the two resources it uses more
+    # of (or by latency, below): HBM (counter bytes per launch over the launch time measured here, against the peak) or vector-ALU issue
+    # slots; `achieved` / `frac` stay the algorithmic bytes against the HBM peak either way.
+    traffic, valu, bound = None, None, "hbm"
+    if dom in counters:
+        e = counters[dom]
+        traffic = e["bytes_per_launch"]
+        if "valu_issue_frac" in e:
+            valu = {"issue_slot_frac": e["valu_issue_frac"], "insts_per_wave": e["valu_per_wave"], "wait_frac": e["wait_frac"],
+                    "source": "profiles/hbm_traffic.json (PMC passes of this configuration)"}
+            if dom_ms > 0:
+                valu["hbm_traffic_frac"] = round(traffic * dom_launches / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+                if e["valu_issue_frac"] > valu["hbm_traffic_frac"]:
+                    bound = "valu"
+                # neither resource a quarter used and the waves parked most of the time: a chain of dependent steps
+                # (the intra wavefront), bound by the latency of its hand-overs
+                if max(e["valu_issue_frac"], valu["hbm_traffic_frac"]) < 0.25 and e["wait_frac"] > 0.6:
+                    bound = "latency"
 
     frames_total = sharding.sum_over_ranks(npic * S * args.steps, dist, device=red_dev)
     value = frames_total / elapsed
@@ -679,7 +703,7 @@ def main():
         "recon_alg_gbps": round(sum(alg_bytes_stream) * args.steps / elapsed / 1e9, 2),
         "recon_alg_gbps_gpu_time": round(sum(alg_bytes_stream[s] for s in groups[0]) / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None,
         "alg_bytes_per_frame": sum(alg_bytes_stream) // (npic * S),
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "roofline": {"bound": bound, "valu": valu, "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                      "alg_bytes_per_launch": int(kb[dom] / max(dom_launches, 1)),
                      "launches_per_step": int(dom_launches), "avg_launch_us": round(dom_ms * 1e3 / max(dom_launches, 1), 3),

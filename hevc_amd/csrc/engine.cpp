@@ -187,7 +187,7 @@ struct hevcrecon_ctx {
   // hevcrecon_picture_md5_submit: a stream of its own beside the reconstruction kernels, tickets in flight
   // (a hash kernel runs for milliseconds whatever it hashes: requests go round a few streams so that several overlap)
   hipStream_t md5_streams[4] = {};
-  hipStream_t md5_stream = nullptr;  // the first of them; also says that they exist
+  bool md5_stream = false;  // do they exist yet?
   hipEvent_t md5_fork = nullptr;  // recorded on the kernels' stream, waited for by the hash streams
   Md5Slot md5_slots[kMd5Slots];
   int64_t md5_next = 0;
@@ -774,18 +774,22 @@ static int stage_packed(hevcrecon_syntax *s) {
     s->up_host = s->host;
     s->up_dev = s->dev;
   }
-  std::memcpy(s->up_host + s->off_runs, k.runs.data(), k.runs.size() * sizeof(Part4));
-  std::memcpy(s->up_host + s->off_runoff, k.ctu_run_off.data(), k.ctu_run_off.size() * sizeof(uint32_t));
-  for (int i = 0; i < 4; i++) std::memcpy(s->up_host + s->off_tu[i], k.tu[i].data(), k.tu[i].size() * sizeof(TuItem));
-  std::memcpy(s->up_host + s->off_coeff, k.coeff.data(), k.coeff.size() * sizeof(uint32_t));
-  std::memcpy(s->up_host + s->off_intra, k.intra.data(), k.intra.size() * sizeof(IntraItem));
-  std::memcpy(s->up_host + s->off_ictu, k.ictu.data(), k.ictu.size() * sizeof(IntraCtu));
-  std::memcpy(s->up_host + s->off_lvlc, k.rounds.data(), k.rounds.size() * sizeof(uint16_t));
-  std::memcpy(s->up_host + s->off_wave, k.wave_off.data(), k.wave_off.size() * sizeof(int32_t));
-  std::memcpy(s->up_host + s->off_sao, k.sao.data(), k.sao.size() * sizeof(SaoCtu));
-  std::memcpy(s->up_host + s->off_ctui, k.ctu_info.data(), k.ctu_info.size() * sizeof(CtuInfo));
-  for (int i = 0; i < 3; i++) std::memcpy(s->up_host + s->off_mct[i], k.mc_tile[i].data(), k.mc_tile[i].size() * sizeof(McTile));
-  std::memcpy(s->up_host + s->off_mcb, k.mc_blk.data(), k.mc_blk.size() * sizeof(McBlk));
+  // (an empty vector's data() may be null, which memcpy must not be given even for zero bytes)
+  auto put = [&](size_t off, const auto &v) {
+    if (!v.empty()) std::memcpy(s->up_host + off, v.data(), v.size() * sizeof(v[0]));
+  };
+  put(s->off_runs, k.runs);
+  put(s->off_runoff, k.ctu_run_off);
+  for (int i = 0; i < 4; i++) put(s->off_tu[i], k.tu[i]);
+  put(s->off_coeff, k.coeff);
+  put(s->off_intra, k.intra);
+  put(s->off_ictu, k.ictu);
+  put(s->off_lvlc, k.rounds);
+  put(s->off_wave, k.wave_off);
+  put(s->off_sao, k.sao);
+  put(s->off_ctui, k.ctu_info);
+  for (int i = 0; i < 3; i++) put(s->off_mct[i], k.mc_tile[i]);
+  put(s->off_mcb, k.mc_blk);
   std::memcpy(s->up_host + s->off_scal, &k.scaling, sizeof(ScalingTables));
   std::memcpy(s->up_host + s->off_wp, &k.wp, sizeof(WpTables));
   return queue_upload(s);
@@ -1571,8 +1575,8 @@ static int md5_submit_impl(hevcrecon_ctx *c, int n, const int *pic_ids, int64_t 
     if (const char *e = std::getenv("HEVCRECON_HASH_PRIORITY"))  // experiments: "normal" puts the hash streams on a par with the kernels' stream
       if (!std::strcmp(e, "normal")) least = 0;
     for (int i = 0; i < 4; i++) HIPCHK(c, hipStreamCreateWithPriority(&c->md5_streams[i], hipStreamNonBlocking, least));
-    c->md5_stream = c->md5_streams[0];
     HIPCHK(c, hipEventCreateWithFlags(&c->md5_fork, hipEventDisableTiming));
+    c->md5_stream = true;
   }
   Md5Slot &m = c->md5_slots[c->md5_next % kMd5Slots];
   if (m.ticket >= 0) return fail(c, "too many picture hashes in flight: collect earlier tickets with hevcrecon_picture_md5_poll or _wait first");

@@ -542,8 +542,8 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
   // TComDataCU::clipMv (TLibCommon/TComDataCU.cpp:3207-3219): the range depends on the coding unit's origin.
   const int cusize = 64 >> (p.flags & P4_DEPTH_MASK);
   const int cux = x & ~(cusize - 1), cuy = y & ~(cusize - 1);
-  const int hmax = (s.w + 8 - cux - 1) << 2, hmin = (-64 - 8 - cux + 1) << 2;
-  const int vmax = (s.h + 8 - cuy - 1) << 2, vmin = (-64 - 8 - cuy + 1) << 2;
+  const int hmax = (s.w + 8 - cux - 1) * 4, hmin = (-64 - 8 - cux + 1) * 4;
+  const int vmax = (s.h + 8 - cuy - 1) * 4, vmin = (-64 - 8 - cuy + 1) * 4;
   bool use0 = p.ref_idx[0] >= 0, use1 = p.ref_idx[1] >= 0;
   // TComPrediction::xCheckIdenticalMotion (TLibCommon/TComPrediction.cpp:396-411); not with weighted bi-prediction
   const WpTables *wp = WP ? J.wp : nullptr;
@@ -800,7 +800,7 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
   constexpr int HIT = (LYP + TC + NTHR - 1) / NTHR;  // H items per lane and list
   constexpr int LVL = TS == 64 ? 0 : TS == 32 ? 1 : 2;
   __shared__ __attribute__((aligned(16))) unsigned P_y[2][NPY * TS];
-  __shared__ __attribute__((aligned(16))) unsigned P_c[2][2][NPC * CS];
+  __shared__ __attribute__((aligned(16))) unsigned P_c[2][2 * NPC * CS];
   const PicJob &J = jobs[blockIdx.y];
   // XCD-contiguous order: workgroups go to the 8 XCDs round-robin; consecutive regions share cache lines
   const int n = J.n_mc_tile[LVL], per_xcd = (n + 7) >> 3;
@@ -918,7 +918,7 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
             for (int i = 0; i < 8; i++) h[rr][i] = hr_sdot4z((i & 3) ? hr_alignbyte(x[(i >> 2) + 1], x[i >> 2], i & 3) : x[i >> 2], c4);
           }
         }
-        uint4 *dst = chroma ? (uint4 *)&P_c[l][0][comp * (NPC * CS) + p * CS + 8 * o] : (uint4 *)&P_y[l][p * TS + 8 * o];
+        uint4 *dst = chroma ? (uint4 *)&P_c[l][comp * (NPC * CS) + p * CS + 8 * o] : (uint4 *)&P_y[l][p * TS + 8 * o];
         dst[0] = make_uint4(pack16(h[0][0], h[1][0]), pack16(h[0][1], h[1][1]), pack16(h[0][2], h[1][2]), pack16(h[0][3], h[1][3]));
         dst[1] = make_uint4(pack16(h[0][4], h[1][4]), pack16(h[0][5], h[1][5]), pack16(h[0][6], h[1][6]), pack16(h[0][7], h[1][7]));
       }
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
 #pragma unroll
       for (int l = 0; l < 2; l++) {
         if (t.ref[l] < 0 || vc >= CT) continue;
-        const uint4 *src = (const uint4 *)&P_c[l][0][comp * (NPC * CS) + rp * CS + 4 * q];
+        const uint4 *src = (const uint4 *)&P_c[l][comp * (NPC * CS) + rp * CS + 4 * q];
         if (vid_c[l]) {
           const uint4 a = src[0], b = src[CS / 4];
           const unsigned qa[4] = {a.x, a.y, a.z, a.w}, qb[4] = {b.x, b.y, b.z, b.w};
@@ -1150,7 +1150,7 @@ __device__ __forceinline__ void transform_blocks(const PicJob &J, const SeqInfo 
         if (sl_shift > 0)
           d = clip3i(-32768, 32767, (dq[k] * coef + (1 << (sl_shift - 1))) >> sl_shift);
         else
-          d = clip3i(-32768, 32767, (clip3i(-sl_lim, sl_lim - 1, dq[k]) * coef) << (-sl_shift));
+          d = clip3i(-32768, 32767, (clip3i(-sl_lim, sl_lim - 1, dq[k]) * coef) * (1 << (-sl_shift)));
       }
       if (tskip) tmp[t_local][k][c] = d;  // transform-skip blocks bypass both passes: keep the de-quantised block as it is
       if (bypass) tmp[t_local][k][c] = dq[k];
@@ -1193,7 +1193,7 @@ __device__ __forceinline__ void transform_blocks(const PicJob &J, const SeqInfo 
   if (bypass) {
     const int up = pcm ? bd - (comp ? s.pcm_bd_c : s.pcm_bd_y) : 0;
 #pragma unroll
-    for (int x = 0; x < N; x++) res[x] = row[x] << up;
+    for (int x = 0; x < N; x++) res[x] = row[x] * (1 << up);
   } else if (tskip) {
     const int ts = 15 - bd - LOG2N;  // > 0 for every supported bit depth
 #pragma unroll
@@ -2055,7 +2055,7 @@ __global__ __launch_bounds__(256) void k_deblock(const PicJob *jobs, SeqInfo s) 
       for (int k = 0; k < 2; k++) {
         HR_GLOBAL pel_t *o = sp + k * line;
         const int m2 = o[-2 * step], m3 = o[-step], m4 = o[0], m5 = o[step];
-        const int delta = clip3i(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
+        const int delta = clip3i(-tc, tc, ((((m4 - m3) * 4) + m2 - m5 + 4) >> 3));
         if (!keep_p) o[-step] = (pel_t)clip3i(0, maxv, m3 + delta);
         if (!keep_q) o[0] = (pel_t)clip3i(0, maxv, m4 - delta);
       }
