@@ -14,7 +14,7 @@
 //                                dependency level; IntraCtu ictu[...] one entry per CTU that holds intra blocks,
 //                                sorted by CTU wave (a CTU's wave is one more than the highest wave among the
 //                                neighbouring CTUs whose intra blocks its own blocks read)
-//   * McTile  mc_tile[3][...] / McBlk mc_blk[...]  regions with uniform / mixed motion
+//   * McTile  mc_tile[3][...] / McBlk mc_blk[...], mc_blk8[...]  regions with uniform / mixed motion
 //   * SaoCtu  sao[nCtu*3]        SAO parameters per CTU and component
 //   * CtuInfo ctu_info[nCtu]     only for pictures with per-slice filter parameters or uncrossed slice / tile boundaries
 // Sample planes are uint8 for 8-bit sequences and uint16 otherwise, with no margin: kernels clamp
@@ -66,7 +66,9 @@ struct TuItem {
 
 // Motion compensation work lists.  Square luma regions (a whole CTU, else its 32x32 quadrants, else their 16x16
 // quadrants) whose units all carry the same (clipped) motion go to mc_tile[0..2] and are predicted as one
-// block; the 16x16 regions left over go to mc_blk and are predicted 4x4 unit by 4x4 unit from the motion records.
+// block; what is left of a 16x16 region goes by 8x8 quadrants: in pictures of 8-bit samples a quadrant whose four units
+// carry the same motion to mc_blk8 (predicted as one 8x8 block, the motion taken from its first unit's record), every
+// other quadrant with an inter unit to mc_blk, predicted 4x4 unit by 4x4 unit from the motion records.
 struct McTile {
   uint16_t x, y;     /* luma position of the region */
   int16_t mv[2][2];  /* [list][hor, ver], quarter luma samples, already clipped */
@@ -74,7 +76,7 @@ struct McTile {
   uint8_t pad[2];
 };
 struct McBlk {
-  uint16_t x, y; /* luma position of the region */
+  uint16_t x, y; /* luma position of the 8x8 block */
 };
 
 // Capacity of the intra kernel's per-CTU tables.  A 64x64 CTU holds at most 256 luma + 2 x 64 chroma 4x4 blocks, and
@@ -202,8 +204,8 @@ struct PicJob {
   const uint32_t *ctu_run_off; /* first run of every CTU, + the total */
   int32_t need_expand;         /* rec4 has not been expanded from the runs since the last upload */
   const McTile *mc_tile[3]; /* 64x64, 32x32, 16x16 */
-  const McBlk *mc_blk;
-  int32_t n_mc_tile[3], n_mc_blk;
+  const McBlk *mc_blk, *mc_blk8; /* 8x8 blocks predicted unit by unit / as one block */
+  int32_t n_mc_tile[3], n_mc_blk, n_mc_blk8;
   const TuItem *tu[4];
   int32_t n_tu[4];
   const uint32_t *coeff; /* sparse: per block a count, then (position | value << 16) words */

@@ -216,7 +216,7 @@ struct hevcrecon_syntax {
   bool expanded = false;       // rec4 has been expanded from the uploaded runs
   int64_t last_batch = -1;     // last batch whose kernels read the device copy
   int64_t upload_seq = -1;     // number of the batch of copies that carried the last upload
-  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_ctui = 0, off_mct[3] = {0, 0, 0}, off_mcb = 0, off_scal = 0, off_wp = 0;
+  size_t off_rec4 = 0, off_tu[4] = {0, 0, 0, 0}, off_coeff = 0, off_intra = 0, off_ictu = 0, off_lvlc = 0, off_wave = 0, off_sao = 0, off_ctui = 0, off_mct[3] = {0, 0, 0}, off_mcb = 0, off_mcb8 = 0, off_scal = 0, off_wp = 0;
   bool uploaded = false;
   std::string err;
 };
@@ -738,6 +738,7 @@ static int stage_packed(hevcrecon_syntax *s) {
   s->off_ctui = place(k.ctu_info.size() * sizeof(CtuInfo));
   for (int i = 0; i < 3; i++) s->off_mct[i] = place(k.mc_tile[i].size() * sizeof(McTile));
   s->off_mcb = place(k.mc_blk.size() * sizeof(McBlk));
+  s->off_mcb8 = place(k.mc_blk8.size() * sizeof(McBlk));
   s->off_scal = place(sizeof(ScalingTables));
   s->off_wp = place(sizeof(WpTables));
   const size_t upload_bytes = off;
@@ -790,6 +791,7 @@ static int stage_packed(hevcrecon_syntax *s) {
   put(s->off_ctui, k.ctu_info);
   for (int i = 0; i < 3; i++) put(s->off_mct[i], k.mc_tile[i]);
   put(s->off_mcb, k.mc_blk);
+  put(s->off_mcb8, k.mc_blk8);
   std::memcpy(s->up_host + s->off_scal, &k.scaling, sizeof(ScalingTables));
   std::memcpy(s->up_host + s->off_wp, &k.wp, sizeof(WpTables));
   return queue_upload(s);
@@ -811,8 +813,8 @@ extern "C" int hevcrecon_syntax_finish(hevcrecon_syntax *s, const hevcrecon_pic_
 // imports into an object of its context and reconstructs.  Position independent, checked on import.
 namespace {
 const uint32_t kBlobMagic = 0x42525648;  // "HVRB"
-const uint32_t kBlobVersion = 1;
-enum { BL_RUNS, BL_RUNOFF, BL_TU0, BL_TU1, BL_TU2, BL_TU3, BL_COEFF, BL_INTRA, BL_ICTU, BL_ROUNDS, BL_WAVE, BL_SAO, BL_CTUI, BL_MCT0, BL_MCT1, BL_MCT2, BL_MCB, BL_SLICES, BL_COUNT };
+const uint32_t kBlobVersion = 2;
+enum { BL_RUNS, BL_RUNOFF, BL_TU0, BL_TU1, BL_TU2, BL_TU3, BL_COEFF, BL_INTRA, BL_ICTU, BL_ROUNDS, BL_WAVE, BL_SAO, BL_CTUI, BL_MCT0, BL_MCT1, BL_MCT2, BL_MCB, BL_MCB8, BL_SLICES, BL_COUNT };
 struct BlobHeader {
   uint32_t magic, version;
   uint64_t total_bytes;
@@ -826,7 +828,7 @@ struct BlobHeader {
   WpTables wp;
 };
 const size_t kBlobElem[BL_COUNT] = {sizeof(Part4), 4, sizeof(TuItem), sizeof(TuItem), sizeof(TuItem), sizeof(TuItem), 4, sizeof(IntraItem), sizeof(IntraCtu), 2, 4,
-                                    sizeof(SaoCtu), sizeof(CtuInfo), sizeof(McTile), sizeof(McTile), sizeof(McTile), sizeof(McBlk), sizeof(hevcrecon_slice_params)};
+                                    sizeof(SaoCtu), sizeof(CtuInfo), sizeof(McTile), sizeof(McTile), sizeof(McTile), sizeof(McBlk), sizeof(McBlk), sizeof(hevcrecon_slice_params)};
 size_t blob_header_bytes() { return align_up(sizeof(BlobHeader), 16); }
 template <class T> const void *vec_data(const std::vector<T> &v) { return v.data(); }
 }  // namespace
@@ -837,11 +839,11 @@ extern "C" int hevcrecon_syntax_export(const hevcrecon_syntax *s, void *dst, int
   if (!k.finished) return 1;
   const void *src[BL_COUNT] = {vec_data(k.runs), vec_data(k.ctu_run_off), vec_data(k.tu[0]), vec_data(k.tu[1]), vec_data(k.tu[2]), vec_data(k.tu[3]),
                                vec_data(k.coeff), vec_data(k.intra), vec_data(k.ictu), vec_data(k.rounds), vec_data(k.wave_off), vec_data(k.sao),
-                               vec_data(k.ctu_info), vec_data(k.mc_tile[0]), vec_data(k.mc_tile[1]), vec_data(k.mc_tile[2]), vec_data(k.mc_blk),
+                               vec_data(k.ctu_info), vec_data(k.mc_tile[0]), vec_data(k.mc_tile[1]), vec_data(k.mc_tile[2]), vec_data(k.mc_blk), vec_data(k.mc_blk8),
                                vec_data(k.slices)};
   const size_t cnt[BL_COUNT] = {k.runs.size(), k.ctu_run_off.size(), k.tu[0].size(), k.tu[1].size(), k.tu[2].size(), k.tu[3].size(), k.coeff.size(),
                                 k.intra.size(), k.ictu.size(), k.rounds.size(), k.wave_off.size(), k.sao.size(), k.ctu_info.size(), k.mc_tile[0].size(),
-                                k.mc_tile[1].size(), k.mc_tile[2].size(), k.mc_blk.size(), k.slices.size()};
+                                k.mc_tile[1].size(), k.mc_tile[2].size(), k.mc_blk.size(), k.mc_blk8.size(), k.slices.size()};
   size_t total = blob_header_bytes();
   for (int i = 0; i < BL_COUNT; i++) total += align_up(cnt[i] * kBlobElem[i], 16);
   *bytes = (int64_t)total;
@@ -926,6 +928,7 @@ extern "C" int hevcrecon_syntax_import(hevcrecon_syntax *s, const void *src, int
   take(BL_MCT1, k.mc_tile[1]);
   take(BL_MCT2, k.mc_tile[2]);
   take(BL_MCB, k.mc_blk);
+  take(BL_MCB8, k.mc_blk8);
   take(BL_SLICES, k.slices);
   // what the kernels index with has to lie inside the arrays (the exporting packer guarantees it; a blob is foreign input)
   const size_t n_runs = k.runs.size(), n_intra = k.intra.size(), n_rounds = k.rounds.size(), n_coeff = k.coeff.size();
@@ -949,7 +952,10 @@ extern "C" int hevcrecon_syntax_import(hevcrecon_syntax *s, const void *src, int
         return refuse("packed picture: motion region out of range");
     }
   for (size_t i = 0; i < k.mc_blk.size(); i++)
-    if (k.mc_blk[i].x >= h.seq.w || k.mc_blk[i].y >= h.seq.h) return refuse("packed picture: motion region out of range");
+    if (k.mc_blk[i].x >= h.seq.w || k.mc_blk[i].y >= h.seq.h || ((k.mc_blk[i].x | k.mc_blk[i].y) & 7)) return refuse("packed picture: motion block out of range");
+  for (size_t i = 0; i < k.mc_blk8.size(); i++)
+    if (k.mc_blk8[i].x >= h.seq.w || k.mc_blk8[i].y >= h.seq.h || ((k.mc_blk8[i].x | k.mc_blk8[i].y) & 7) || h.seq.bd_y > 8 || h.seq.bd_c > 8)
+      return refuse("packed picture: 8x8 motion block out of range");
   // reference indices as the records hold them (not as the header claims)
   int max_ref[2] = {-1, -1};
   bool no_ref = false;
@@ -1108,7 +1114,7 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
   const SeqInfo &s = c->si;
   PicJob *jh = ws.jobs_host, *jd = ws.jobs_dev;
   if (c->ring_used[ws.slot]) HIPCHK(c, hipEventSynchronize(c->ring_ev[ws.slot]));
-  int max_tu[4] = {0, 0, 0, 0}, max_small_groups = 0, max_levels = 0, max_mct[3] = {0, 0, 0}, max_mcb = 0;
+  int max_tu[4] = {0, 0, 0, 0}, max_small_groups = 0, max_levels = 0, max_mct[3] = {0, 0, 0}, max_mcb = 0, max_mcb8 = 0;
   bool any_deblock = false, any_sao = false, any_wp = false, any_expand = false;
   for (int i = 0; i < n; i++) {
     hevcrecon_syntax *y = syn[i];
@@ -1143,6 +1149,9 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
     j.mc_blk = (const McBlk *)(y->up_dev + y->off_mcb);
     j.n_mc_blk = (int)k.mc_blk.size();
     max_mcb = std::max(max_mcb, j.n_mc_blk);
+    j.mc_blk8 = (const McBlk *)(y->up_dev + y->off_mcb8);
+    j.n_mc_blk8 = (int)k.mc_blk8.size();
+    max_mcb8 = std::max(max_mcb8, j.n_mc_blk8);
     for (int t = 0; t < 4; t++) {
       j.tu[t] = (const TuItem *)(y->up_dev + y->off_tu[t]);
       j.n_tu[t] = (int)k.tu[t].size();
@@ -1276,15 +1285,18 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
     Timed tm(c, K_OTHER, 1, !ws.fixed);
     hr_launch(K_OTHER, jd, n, s, c->stream, 0, 0);
   }
-  if (max_mct[0] > 0 || max_mct[1] > 0 || max_mct[2] > 0 || max_mcb > 0) {
+  if (max_mct[0] > 0 || max_mct[1] > 0 || max_mct[2] > 0 || max_mcb > 0 || max_mcb8 > 0) {
     // arg = 0..2: uniform regions of 64, 32, 16 samples; 3: the mixed rest; +4: the variants with explicit weights
     const int cls[4] = {K_INTER, K_INTER_T32, K_INTER_T16, K_INTER_BLK};
-    for (int t = 0; t < 4; t++) {
-      const int cnt = t < 3 ? max_mct[t] : max_mcb;
-      if (cnt > 0) {
+    for (int t = 0; t < 3; t++)
+      if (max_mct[t] > 0) {
         Timed tm(c, cls[t], 1, !ws.fixed);
-        hr_launch(K_INTER, jd, n, s, c->stream, t + (any_wp ? 4 : 0), cnt);
+        hr_launch(K_INTER, jd, n, s, c->stream, t + (any_wp ? 4 : 0), max_mct[t]);
       }
+    if (max_mcb > 0 || max_mcb8 > 0) {  // the mixed rest: 8x8 blocks of one motion, then unit by unit (one timer for both)
+      Timed tm(c, cls[3], (max_mcb > 0) + (max_mcb8 > 0), !ws.fixed);
+      if (max_mcb8 > 0) hr_launch(K_INTER, jd, n, s, c->stream, 8 + (any_wp ? 1 : 0), max_mcb8);
+      if (max_mcb > 0) hr_launch(K_INTER, jd, n, s, c->stream, 3 + (any_wp ? 4 : 0), max_mcb);
     }
   }
   {

@@ -682,15 +682,16 @@ __device__ __forceinline__ void inter_unit(const PicJob &J, const SeqInfo &s, in
   }
 }
 
-// k_inter_blk: 16x16 regions with mixed motion.  One wave per four regions, one lane per 4x4 unit.
+// k_inter_blk: the 8x8 blocks of mixed motion (and, in 16-bit pictures, every 8x8 block outside the uniform regions).
+// One wave per sixteen blocks, one lane per 4x4 unit.
 template <typename pel_t, bool WP>
 __global__ __launch_bounds__(256) void k_inter_blk(const PicJob *jobs, SeqInfo s) {
   const PicJob &J = jobs[blockIdx.y];
-  const int r = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int r = blockIdx.x * 64 + (threadIdx.x >> 2);
   if (r >= J.n_mc_blk) return;
   const McBlk b = J.mc_blk[r];
-  const int u = threadIdx.x & 15;
-  const int ux = (b.x >> 2) + (u & 3), uy = (b.y >> 2) + (u >> 2);
+  const int u = threadIdx.x & 3;
+  const int ux = (b.x >> 2) + (u & 1), uy = (b.y >> 2) + (u >> 1);
   if (ux >= s.uw || uy >= s.uh) return;
   inter_unit<pel_t, WP>(J, s, ux, uy);
 }
@@ -1044,6 +1045,195 @@ __global__ __launch_bounds__(NTHR, (sizeof(pel_t) == 1 ? 8 : 4)) void k_inter_ti
           }
         }
       }
+    }
+  }
+}
+
+// ---- k_inter_blk8: 8x8 blocks of one motion inside regions of mixed motion (8-bit pictures) ----------------------
+// The two phases of k_inter_tile at the smallest size that still shares work between lanes; a workgroup of four waves
+// takes 16 blocks, and the kinds of work are dealt out by wave so that no wave runs two of them one after the other:
+//   phase H  waves 0, 1: eight lanes per block, each a pair of the 16 luma window rows (15 are needed; 8 outputs);
+//            waves 2, 3: eight lanes per block, each a pair of the 8 window rows of Cb / Cr (7 needed; 4 outputs);
+//            16 bytes per row straight from the reference picture;
+//   phase V  waves 0, 1: eight lanes per block, two rows x four columns of luma each; wave 2: four lanes per block,
+//            two rows x four columns of a chroma block.
+// The motion comes from the record of the block's first unit, resolved as in inter_unit (clipMv, identical motion) by
+// one lane per block and handed to the others through LDS.  A wave serves several blocks with different motions, so
+// nothing is wave-uniform here: the tap tables are read from LDS by fraction, and a zero fraction runs through the
+// identity taps (same result, no branch).
+struct BlkMotion {
+  int x, y, z, w;
+};
+template <bool WP>
+__global__ __launch_bounds__(256) void k_inter_blk8(const PicJob *jobs, SeqInfo s) {
+  __shared__ __attribute__((aligned(16))) unsigned P_y[16][2][8 * 8];  // [block][list][row pair * 8 + column]: rows 2p, 2p+1 in one dword
+  __shared__ __attribute__((aligned(16))) unsigned P_c[16][2][2 * 4 * 4];  // [block][list][component * 16 + row pair * 4 + column]
+  __shared__ __attribute__((aligned(16))) int mot[16][8];  // per block: x, y, mvx[0], mvy[0], mvx[1], mvy[1], ref[0], ref[1] (-1: list not used)
+  __shared__ unsigned tab_l[4 * 12], tab_c[8 * 8];
+  const PicJob &J = jobs[blockIdx.y];
+  if ((int)blockIdx.x * 16 >= J.n_mc_blk8) return;
+  const int tid = threadIdx.x;
+  const WpTables *wp = WP ? J.wp : nullptr;
+  if (tid < 16) {
+    const int r = (int)blockIdx.x * 16 + tid;
+    int m[8] = {0, 0, 0, 0, 0, 0, -1, -1};
+    if (r < J.n_mc_blk8) {
+      const McBlk b = J.mc_blk8[r];
+      const int x = b.x, y = b.y;
+      const Part4 p = J.rec4[(size_t)(y >> 2) * s.uw + (x >> 2)];
+      // TComDataCU::clipMv (TLibCommon/TComDataCU.cpp:3207-3219): the range depends on the coding unit's origin.
+      const int cusize = 64 >> (p.flags & P4_DEPTH_MASK);
+      const int cux = x & ~(cusize - 1), cuy = y & ~(cusize - 1);
+      const int hmax = (s.w + 8 - cux - 1) * 4, hmin = (-64 - 8 - cux + 1) * 4;
+      const int vmax = (s.h + 8 - cuy - 1) * 4, vmin = (-64 - 8 - cuy + 1) * 4;
+      bool use0 = p.ref_idx[0] >= 0 && !(p.flags & P4_INTRA), use1 = p.ref_idx[1] >= 0 && !(p.flags & P4_INTRA);
+      // TComPrediction::xCheckIdenticalMotion (TLibCommon/TComPrediction.cpp:396-411); not with weighted bi-prediction
+      if (use0 && use1 && J.slice_type == 0 && !wp && J.ref_poc[0][p.ref_idx[0]] == J.ref_poc[1][p.ref_idx[1]] && p.mv[0][0] == p.mv[1][0] &&
+          p.mv[0][1] == p.mv[1][1])
+        use1 = false;
+      m[0] = x, m[1] = y;
+      m[2] = min(hmax, max(hmin, (int)p.mv[0][0])), m[3] = min(vmax, max(vmin, (int)p.mv[0][1]));
+      m[4] = min(hmax, max(hmin, (int)p.mv[1][0])), m[5] = min(vmax, max(vmin, (int)p.mv[1][1]));
+      m[6] = use0 ? p.ref_idx[0] : -1, m[7] = use1 ? p.ref_idx[1] : -1;
+    }
+    *(uint4 *)&mot[tid][0] = make_uint4((unsigned)m[0], (unsigned)m[1], (unsigned)m[2], (unsigned)m[3]);
+    *(uint4 *)&mot[tid][4] = make_uint4((unsigned)m[4], (unsigned)m[5], (unsigned)m[6], (unsigned)m[7]);
+  }
+  if (tid >= 64 && tid < 112) tab_l[tid - 64] = kLumaTab[(tid - 64) / 12][(tid - 64) % 12];
+  if (tid >= 128 && tid < 192) tab_c[tid - 128] = kChromaTab[(tid - 128) >> 3][(tid - 128) & 7];
+  __syncthreads();
+
+  // ---- phase H ----
+  {
+    const bool luma = tid < 128;
+    const int k = luma ? tid : tid - 128, g = k >> 3;
+    const uint4 u0 = *(const uint4 *)&mot[g][0], u1 = *(const uint4 *)&mot[g][4];
+    const BlkMotion m0 = {(int)u0.x, (int)u0.y, (int)u0.z, (int)u0.w}, m1 = {(int)u1.x, (int)u1.y, (int)u1.z, (int)u1.w};
+    const int x = m0.x, y = m0.y;
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      const int ri = l ? m1.w : m1.z, mvx = l ? m1.x : m0.z, mvy = l ? m1.y : m0.w;
+      if (ri < 0) continue;
+      unsigned w[2][4];
+      if (luma) {
+        const int rp = k & 7;
+        const int wx0 = x + (mvx >> 2) - 3, wy0 = y + (mvy >> 2) - 3;
+        const bool fast = wx0 >= 0 && wx0 + 15 < s.w;
+        const HR_GLOBAL uint8_t *base = (const HR_GLOBAL uint8_t *)J.ref[l][ri][0];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+          tile_row_load(base + (size_t)clip3i(0, s.h - 1, wy0 + min(2 * rp + rr, 14)) * s.stride_y, wx0, s.w, fast, w[rr]);
+        const unsigned c_lo = tab_l[(mvx & 3) * 12], c_hi = tab_l[(mvx & 3) * 12 + 1];
+        int h[2][8];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+          unsigned xs[4], a[12];
+#pragma unroll
+          for (int i = 0; i < 4; i++) xs[i] = w[rr][i] ^ 0x80808080u;
+#pragma unroll
+          for (int i = 0; i < 12; i++) a[i] = (i & 3) ? hr_alignbyte(xs[(i >> 2) + 1], xs[i >> 2], i & 3) : xs[i >> 2];
+#pragma unroll
+          for (int i = 0; i < 8; i++) h[rr][i] = hr_sdot4(a[i + 4], c_hi, hr_sdot4z(a[i], c_lo));
+        }
+        uint4 *dst = (uint4 *)&P_y[g][l][rp * 8];
+        dst[0] = make_uint4(pack16(h[0][0], h[1][0]), pack16(h[0][1], h[1][1]), pack16(h[0][2], h[1][2]), pack16(h[0][3], h[1][3]));
+        dst[1] = make_uint4(pack16(h[0][4], h[1][4]), pack16(h[0][5], h[1][5]), pack16(h[0][6], h[1][6]), pack16(h[0][7], h[1][7]));
+      } else {
+        const int comp = (k >> 2) & 1, rp = k & 3;
+        const int cwx0 = (x >> 1) + (mvx >> 3) - 1, cwy0 = (y >> 1) + (mvy >> 3) - 1;
+        const bool fast = cwx0 >= 0 && cwx0 + 15 < s.cw;
+        const HR_GLOBAL uint8_t *base = (const HR_GLOBAL uint8_t *)(comp ? J.ref[l][ri][2] : J.ref[l][ri][1]);
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+          tile_row_load(base + (size_t)clip3i(0, s.ch - 1, cwy0 + min(2 * rp + rr, 6)) * s.stride_c, cwx0, s.cw, fast, w[rr]);
+        const unsigned c4 = tab_c[(mvx & 7) * 8];
+        int h[2][4];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+          const unsigned x0 = w[rr][0] ^ 0x80808080u, x1 = w[rr][1] ^ 0x80808080u;
+#pragma unroll
+          for (int i = 0; i < 4; i++) h[rr][i] = hr_sdot4z(i ? hr_alignbyte(x1, x0, i) : x0, c4);
+        }
+        *(uint4 *)&P_c[g][l][comp * 16 + rp * 4] = make_uint4(pack16(h[0][0], h[1][0]), pack16(h[0][1], h[1][1]), pack16(h[0][2], h[1][2]), pack16(h[0][3], h[1][3]));
+      }
+    }
+  }
+  __syncthreads();
+  if (tid >= 192) return;
+
+  // ---- phase V: two rows x four columns per lane, then the uni- or bi-prediction rounding ----
+  int acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  if (tid < 128) {
+    const int g = tid >> 3, q = tid & 1, rp = (tid >> 1) & 3;
+    const uint4 u0 = *(const uint4 *)&mot[g][0], u1 = *(const uint4 *)&mot[g][4];
+    const BlkMotion m0 = {(int)u0.x, (int)u0.y, (int)u0.z, (int)u0.w}, m1 = {(int)u1.x, (int)u1.y, (int)u1.z, (int)u1.w};
+    const int x = m0.x, y = m0.y, r0 = m1.z, r1 = m1.w;
+    if (r0 < 0 && r1 < 0) return;  // no block here (the list ended inside the workgroup)
+    const PredRound R = pred_round(wp, r0, r1, 0, s.bd_y);
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      if ((l ? r1 : r0) < 0) continue;
+      const unsigned *lt = &tab_l[((l ? m1.y : m0.w) & 3) * 12];
+      const unsigned e0 = lt[2], e1 = lt[3], e2 = lt[4], e3 = lt[5], o0 = lt[6], o1 = lt[7], o2 = lt[8], o3 = lt[9], o4 = lt[10];
+      const uint4 *src = (const uint4 *)&P_y[g][l][rp * 8 + 4 * q];
+      unsigned qq[5][4];
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        const uint4 a = src[2 * i];  // row pair rp + i
+        qq[i][0] = a.x, qq[i][1] = a.y, qq[i][2] = a.z, qq[i][3] = a.w;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int a0 = hr_sdot2(qq[3][c], e3, hr_sdot2(qq[2][c], e2, hr_sdot2(qq[1][c], e1, hr_sdot2z(qq[0][c], e0)))) >> 6;
+        const int a1 = hr_sdot2(qq[4][c], o4, hr_sdot2(qq[3][c], o3, hr_sdot2(qq[2][c], o2, hr_sdot2(qq[1][c], o1, hr_sdot2z(qq[0][c], o0))))) >> 6;
+        const int wl = l ? R.w[1] : R.w[0];
+        acc[0][c] += WP ? __mul24(wl, a0) : a0;
+        acc[1][c] += WP ? __mul24(wl, a1) : a1;
+      }
+    }
+    const int maxv = (1 << s.bd_y) - 1;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      int px[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) px[c] = tile_px(acc[j][c], R.add, R.sh, maxv, WP ? R.post : 0);
+      *(HR_GLOBAL unsigned *)((HR_GLOBAL uint8_t *)J.rec[0] + (size_t)(y + 2 * rp + j) * s.stride_y + x + 4 * q) = pack4(px[0], px[1], px[2], px[3]);
+    }
+  } else {
+    const int k = tid - 128, g = k >> 2, comp = (k >> 1) & 1, rp = k & 1;
+    const uint4 u0 = *(const uint4 *)&mot[g][0], u1 = *(const uint4 *)&mot[g][4];
+    const BlkMotion m0 = {(int)u0.x, (int)u0.y, (int)u0.z, (int)u0.w}, m1 = {(int)u1.x, (int)u1.y, (int)u1.z, (int)u1.w};
+    const int x = m0.x, y = m0.y, r0 = m1.z, r1 = m1.w;
+    if (r0 < 0 && r1 < 0) return;
+    const PredRound R = pred_round(wp, r0, r1, 1 + comp, s.bd_c);
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+      if ((l ? r1 : r0) < 0) continue;
+      const unsigned *ct = &tab_c[((l ? m1.y : m0.w) & 7) * 8];
+      const unsigned e0 = ct[1], e1 = ct[2], o0 = ct[3], o1 = ct[4], o2 = ct[5];
+      const uint4 *src = (const uint4 *)&P_c[g][l][comp * 16 + rp * 4];
+      unsigned qq[3][4];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        const uint4 a = src[i];  // row pair rp + i
+        qq[i][0] = a.x, qq[i][1] = a.y, qq[i][2] = a.z, qq[i][3] = a.w;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int a0 = hr_sdot2(qq[1][c], e1, hr_sdot2z(qq[0][c], e0)) >> 6;
+        const int a1 = hr_sdot2(qq[2][c], o2, hr_sdot2(qq[1][c], o1, hr_sdot2z(qq[0][c], o0))) >> 6;
+        const int wl = l ? R.w[1] : R.w[0];
+        acc[0][c] += WP ? __mul24(wl, a0) : a0;
+        acc[1][c] += WP ? __mul24(wl, a1) : a1;
+      }
+    }
+    const int maxv = (1 << s.bd_c) - 1;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      int px[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) px[c] = tile_px(acc[j][c], R.add, R.sh, maxv, WP ? R.post : 0);
+      *(HR_GLOBAL unsigned *)((HR_GLOBAL uint8_t *)J.rec[1 + comp] + (size_t)((y >> 1) + 2 * rp + j) * s.stride_c + (x >> 1)) = pack4(px[0], px[1], px[2], px[3]);
     }
   }
 }
@@ -2509,7 +2699,7 @@ template <typename pel_t>
 static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, hipStream_t st, int arg, int arg2) {
   switch (kind) {
     case K_INTER:
-      // arg = 0..2: uniform regions of 64 / 32 / 16 samples, 3: mixed regions, +4: some picture of the batch uses
+      // arg = 0..2: uniform regions of 64 / 32 / 16 samples, 3: 8x8 blocks unit by unit, +4: some picture of the batch uses
       // explicit weighted prediction; arg2 = the largest count of such regions over the batch.  Tile grid.x is a
       // multiple of 8, so that blockIdx.x & 7 is the XCD for every picture of the batch.
       {
@@ -2521,8 +2711,13 @@ static void launch_all_t(int kind, const PicJob *jobs, int n, const SeqInfo &s, 
         if (arg == 5) LAUNCH((k_inter_tile<pel_t, 32, 128, true>), g, dim3(128), st, jobs, s);
         if (arg == 6) LAUNCH((k_inter_tile<pel_t, 16, 64, true>), g, dim3(64), st, jobs, s);
       }
-      if (arg == 3) LAUNCH((k_inter_blk<pel_t, false>), dim3((arg2 + 15) / 16, n), dim3(256), st, jobs, s);
-      if (arg == 7) LAUNCH((k_inter_blk<pel_t, true>), dim3((arg2 + 15) / 16, n), dim3(256), st, jobs, s);
+      if (arg == 3) LAUNCH((k_inter_blk<pel_t, false>), dim3((arg2 + 63) / 64, n), dim3(256), st, jobs, s);
+      if (arg == 7) LAUNCH((k_inter_blk<pel_t, true>), dim3((arg2 + 63) / 64, n), dim3(256), st, jobs, s);
+      // arg = 8, 9 (with explicit weights): 8x8 blocks of one motion, 8-bit pictures only (the packer makes none otherwise)
+      if constexpr (sizeof(pel_t) == 1) {
+        if (arg == 8) LAUNCH((k_inter_blk8<false>), dim3((arg2 + 15) / 16, n), dim3(256), st, jobs, s);
+        if (arg == 9) LAUNCH((k_inter_blk8<true>), dim3((arg2 + 15) / 16, n), dim3(256), st, jobs, s);
+      }
       break;
     case K_TRANSFORM: {
       // arg = 5: the 32x32 blocks, arg2 = their largest count over the batch; arg = 0: the smaller blocks, arg2 = the

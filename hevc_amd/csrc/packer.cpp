@@ -723,7 +723,8 @@ bool PackedPicture::finish(const hevcrecon_pic_params *p) {
 // coding-unit origin), same outcome of TComPrediction::xCheckIdenticalMotion
 // (TLibCommon/TComPrediction.cpp:396-411; never taken with weighted bi-prediction).  Explicit weights depend on
 // the reference indices only, so they are uniform too.  Every CTU is tried whole, then by 32x32 quadrants, then by 16x16
-// blocks; what is left goes to mc_blk (16x16 granularity, predicted unit by unit).
+// blocks; what is left goes by 8x8 quadrants to mc_blk8 (one motion, 8-bit pictures: predicted as a block) and mc_blk
+// (predicted unit by unit).
 namespace {
 enum { MC_NONE, MC_UNIFORM, MC_MIXED };
 }
@@ -843,10 +844,20 @@ void PackedPicture::split_mc(int addr, int x0, int y0, int level) {
     return;
   }
   if (level == 2) {
-    McBlk b;
-    b.x = (uint16_t)x0;
-    b.y = (uint16_t)y0;
-    mc_blk.push_back(b);
+    // by 8x8 quadrants: one of a single motion is predicted as a block where the kernels have a path for that (8-bit
+    // samples), the others unit by unit
+    const bool blocks8 = seq.bd_y <= 8 && seq.bd_c <= 8;
+    for (int q = 0; q < 4; q++) {
+      McBlk b;
+      b.x = (uint16_t)(x0 + (q & 1) * 8);
+      b.y = (uint16_t)(y0 + (q >> 1) * 8);
+      if (b.x >= seq.w || b.y >= seq.h) continue;
+      const int k8 = classify_mc(addr, b.x, b.y, 8, &t);
+      if (k8 == MC_UNIFORM && blocks8)
+        mc_blk8.push_back(b);
+      else if (k8 != MC_NONE)
+        mc_blk.push_back(b);
+    }
     return;
   }
   const int h = size >> 1;
@@ -856,6 +867,7 @@ void PackedPicture::split_mc(int addr, int x0, int y0, int level) {
 void PackedPicture::build_mc_lists() {
   for (int i = 0; i < 3; i++) mc_tile[i].clear();
   mc_blk.clear();
+  mc_blk8.clear();
   if (pp.slice_type == 2) return;
   for (int cy = 0; cy < seq.ctus_h; cy++)
     for (int cx = 0; cx < seq.ctus_w; cx++) split_mc(cy * seq.ctus_w + cx, cx * 64, cy * 64, 0);

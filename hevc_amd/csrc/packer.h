@@ -38,7 +38,8 @@ struct PackedPicture {
   std::vector<CtuInfo> ctu_info;
   bool set_slices(int n, const hevcrecon_slice_params *sl);
   std::vector<McTile> mc_tile[3];   // filled by finish(): 64x64 / 32x32 / 16x16 regions predicted as one block
-  std::vector<McBlk> mc_blk;        // filled by finish(): 16x16 regions predicted unit by unit
+  std::vector<McBlk> mc_blk;        // filled by finish(): 8x8 blocks predicted unit by unit
+  std::vector<McBlk> mc_blk8;       // filled by finish(): 8x8 blocks of one motion inside 16x16 regions of mixed motion (8-bit pictures)
   bool has_bypass;                  // some coding unit is exempt from in-loop filtering (lossless, or IPCM with the filters off)
   bool has_pcm;                     // some coding unit is IPCM
   bool use_scaling;                 // the picture de-quantises with `scaling`

@@ -212,8 +212,8 @@ int hevcrecon_syntax_create_detached(const hevcrecon_seq_params *sp, hevcrecon_s
  * [8] 4x4 records, [9] 4x4 records that are intra, [10] finished flag, [11] CTUs holding intra blocks,
  * [12] sum over those CTUs of their local dependency levels, [13] intra rounds on the critical path (slowest CTU
  * of every wave), [14] intra rounds in total, [15] dependency levels on the critical path,
- * [16..18] motion-compensation regions predicted as one block (64x64, 32x32, 16x16), [19] 16x16 regions predicted
- * unit by unit, [20..22] reference blocks read by the regions of [16..18] (one per list in use),
+ * [16..18] motion-compensation regions predicted as one block (64x64, 32x32, 16x16), [19] 8x8 blocks predicted
+ * unit by unit (blocks of one motion outside those regions are predicted whole and not counted here), [20..22] reference blocks read by the regions of [16..18] (one per list in use),
  * [23..25] luma samples those regions cover inside the picture, [26..28] the same weighted by lists in use,
  * [29] bytes copied to the device for this picture, [30] runs the 4x4 records were coded into,
  * [31] bytes of the sparse coefficient stream. */

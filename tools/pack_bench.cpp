@@ -71,9 +71,11 @@ int main(int argc, char **argv) {
       t_fin += std::chrono::duration<double>(t3 - t2).count();
       packed++;
       bytes += pk.runs.size() * 16 + pk.coeff.size() * 4 + pk.intra.size() * 16 + (pk.mc_tile[0].size() + pk.mc_tile[1].size() + pk.mc_tile[2].size()) * 16 +
-               pk.mc_blk.size() * 4 + (pk.tu[0].size() + pk.tu[1].size() + pk.tu[2].size() + pk.tu[3].size()) * 12;
+               (pk.mc_blk.size() + pk.mc_blk8.size()) * 4 + (pk.tu[0].size() + pk.tu[1].size() + pk.tu[2].size() + pk.tu[3].size()) * 12;
     }
-  printf("{\"pictures\": %ld, \"begin_us\": %.1f, \"add_ctu_us\": %.1f, \"finish_us\": %.1f, \"total_us\": %.1f, \"list_bytes_per_picture\": %zu}\n", packed,
+  printf("{\"last_picture_regions\": {\"tile64\": %zu, \"tile32\": %zu, \"tile16\": %zu, \"blk8\": %zu, \"blk8_by_unit\": %zu}, ", pk.mc_tile[0].size(), pk.mc_tile[1].size(),
+         pk.mc_tile[2].size(), pk.mc_blk8.size(), pk.mc_blk.size());
+  printf("\"pictures\": %ld, \"begin_us\": %.1f, \"add_ctu_us\": %.1f, \"finish_us\": %.1f, \"total_us\": %.1f, \"list_bytes_per_picture\": %zu}\n", packed,
          t_begin / packed * 1e6, t_add / packed * 1e6, t_fin / packed * 1e6, (t_begin + t_add + t_fin) / packed * 1e6, bytes / packed);
   return 0;
 }
