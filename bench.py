@@ -724,11 +724,12 @@ def main():
             t0 = time.perf_counter()
             for gg in range(g, g + 2 * period):
                 W.step(gg, upload=True)
+            t_host = (time.perf_counter() - t0) / 2  # the submitting thread's share: it runs ahead of the device until the rings are full
             sync()
             t_both = (time.perf_counter() - t0) / 2
             g += 2 * period
             result["handover"] = {"bytes_per_frame": up_bytes // (npic * S), "with_reconstruction_frames_per_s": round(npic * S / t_both, 1),
-                                  "link_gbps": round(up_bytes / t_both / 1e9, 2)}
+                                  "link_gbps": round(up_bytes / t_both / 1e9, 2), "host_submit_share": round(t_host / t_both, 3)}
         # ---- fewer streams: 1 and 8 streams of context 0 alone (what one decoder process, or 64 streams over 8 GPUs
         # = 8 per GPU, get out of the device), and all streams each at its own position ----
         progress("side measurements: fewer streams")

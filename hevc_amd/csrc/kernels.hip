@@ -2520,15 +2520,15 @@ __global__ __launch_bounds__(256) void k_sao(const PicJob *jobs, SeqInfo s) {
 // k_expand: run-length coded motion records -> rec4.  One workgroup per CTU, one lane per 4x4 unit.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_expand(const PicJob *jobs, SeqInfo s) {
-  __shared__ uint8_t start_s[256];
+  __shared__ __attribute__((aligned(16))) Part4 runs_s[256];  // the CTU's runs: searched and read here, one trip to memory for all of it
   const PicJob &J = jobs[blockIdx.y];
   if (!J.need_expand) return;
   const Part4 *runs = J.runs;
   const uint32_t *ctu_run_off = J.ctu_run_off;
   Part4 *rec4 = const_cast<Part4 *>(J.rec4);
   const int ctu = blockIdx.x, z = threadIdx.x;
-  const unsigned first = ctu_run_off[ctu], n = ctu_run_off[ctu + 1] - first;
-  if ((unsigned)z < n) start_s[z] = runs[first + z].pad;
+  const unsigned first = ctu_run_off[ctu], n = min(ctu_run_off[ctu + 1] - first, 256u);
+  if ((unsigned)z < n) runs_s[z] = runs[first + z];
   __syncthreads();
   int x = 0, y = 0;
 #pragma unroll
@@ -2542,9 +2542,9 @@ __global__ __launch_bounds__(256) void k_expand(const PicJob *jobs, SeqInfo s) {
   int lo = 0, hi = (int)n - 1;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (start_s[mid] <= z) lo = mid; else hi = mid - 1;
+    if (runs_s[mid].pad <= z) lo = mid; else hi = mid - 1;
   }
-  Part4 r = runs[first + lo];
+  Part4 r = runs_s[lo];
   if (z < r.pad || z > r.pad + r.pad2[0]) {  // not covered: cannot happen with a well-formed list
     atomicOr(J.error_flag, HR_ERR_EXPAND);
     return;
