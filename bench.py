@@ -275,7 +275,6 @@ def end_to_end(device, n_proc, loops=8):
                 "start_up_s": round(sum(t["startup_s"] for t in ts) / n_proc, 3), "gpu_init_s": round(sum(t["engine_init_s"] for t in ts) / n_proc, 3),
                 "hash": "device", "pictures_per_hash_request": round(frames / max(1, sum(t["hash_batches"] for t in ts)), 1),
                 "per_picture_ms": _per_picture_ms(ts)}
-            out["packer_us_per_picture_c"] = round(sum(t["pack_s"] + t["finish_s"] for t in ts) / frames * 1e6, 1)
             # the same decoders behind ONE process that owns the GPU (hevc_amd/hevcrecon_hub): the decoder processes pack on
             # their cores and never open the device; the hub reconstructs what all of them have ready as one batch
             if os.path.exists(HUB_BINARY) and "hub" in stages:
@@ -300,6 +299,9 @@ def end_to_end(device, n_proc, loops=8):
                     out["concurrent_through_hub"] = {"processes": n_proc, "gpu_processes": 1, "frames": frames, "frames_per_s": round(frames / span, 1),
                                                      "pictures_per_batch": float(m.group(1)) if m else None, "hash": "device",
                                                      "per_picture_ms": _per_picture_ms(ts)}
+                    # packing alone, from C, on cores that are all busy decoding (these processes never touch the device:
+                    # with a context of its own a decoder's begin() can wait for the device, which its timer would count)
+                    out["packer_us_per_picture_c"] = round(sum(t["pack_s"] + t["finish_s"] for t in ts) / frames * 1e6, 1)
                 else:
                     out["concurrent_through_hub"] = {"error": (hub_err + " ".join(se.decode("latin1")[-200:] for _, se in res if se))[-400:]}
             # the same with every picture fetched and hashed by the reference on the host thread
@@ -325,6 +327,9 @@ def end_to_end(device, n_proc, loops=8):
             single["engine_behind_reference_cli_frames_per_s_with_start_up"] = round(60 / min(_decode_once(BRIDGE_DECODER, _bridge_env(device, "host")) for _ in range(2)), 2)
             single["reference_cli_frames_per_s_with_start_up"] = round(60 / min(_decode_once(REF_DECODER) for _ in range(2)), 2)
             out["one_process"] = single
+            if "packer_us_per_picture_c" not in out:
+                pm = single["device_hash"]["per_picture_ms"]
+                out["packer_us_per_picture_c"] = round((pm["pack"] + pm["finish"]) * 1e3, 1)
     except (RuntimeError, subprocess.CalledProcessError, OSError) as e:
         out["error"] = str(e)[:300]
     return out

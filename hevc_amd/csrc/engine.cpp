@@ -52,6 +52,15 @@ const int kRing = 16;
 // 1 stream 53 k, 3 streams 64 k, 4 streams 65 k, 8 streams 44 k frames/s; a kernel reading the pinned buffers
 // itself reached only 10 GB/s over the link).
 const int kCopyStreams = 3;
+// How many of them take copies: one.  A batch's kernels wait for an event on every copy stream that holds copies of
+// its pictures, and each such cross-stream wait costs the kernels' stream more than the copy engine gains from a
+// second queue (1080p hand-over of 128 streams: 74.3 k frames/s with three, 82.0 k with two, 82.3 k with one).
+// HEVCRECON_COPY_STREAMS=1..3 for experiments.
+static const int g_copy_used = [] {
+  const char *e = std::getenv("HEVCRECON_COPY_STREAMS");
+  const int n = e ? std::atoi(e) : 1;
+  return n < 1 ? 1 : n > kCopyStreams ? kCopyStreams : n;
+}();
 
 // The copy streams belong to the device, not to a context: several contexts on one GPU (each with a kernel stream of
 // its own) share them, so that the process stays near its four hardware queues.
@@ -702,8 +711,8 @@ extern "C" int hevcrecon_syntax_add_ctu(hevcrecon_syntax *s, int ctu_addr, const
 }
 
 // The packed picture is ready in its pinned staging buffer.  It crosses the host link when the first batch that
-// uses it is submitted: the copies of all pictures of the batch that need one go out together, spread over the copy
-// streams (beside the previous batch's kernels, which the host has queued ahead), then k_expand expands the
+// uses it is submitted: the copies of all pictures of the batch that need one go out together on the copy stream(s)
+// (beside the previous batch's kernels, which the host has queued ahead), then k_expand expands the
 // run-length coded records.
 static int queue_upload(hevcrecon_syntax *s) {
   s->dirty = true;
@@ -1206,11 +1215,11 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
     if (any) {
       // kernels already queued may still read a device copy that is about to be rewritten
       if (newest_reader > c->batch_waited) {
-        for (int k = 0; k < kCopyStreams; k++) HIPCHK(c, hipStreamWaitEvent(c->copy_stream[k], c->batch_ev[newest_reader % kRing], 0));
+        for (int k = 0; k < g_copy_used; k++) HIPCHK(c, hipStreamWaitEvent(c->copy_stream[k], c->batch_ev[newest_reader % kRing], 0));
         c->batch_waited = newest_reader;
       }
       // pictures that lie back to back in the upload ring travel in one copy (cut into pieces of a few megabytes so
-      // that the copy streams share the work)
+      // that several copy streams, when in use, share the work)
       // (in the order of their staging addresses, whatever the order of the batch)
       const size_t kPiece = (size_t)8 << 20;
       hevcrecon_syntax *stale[HR_MAX_BATCH];  // (on the stack: this path allocates nothing)
@@ -1227,7 +1236,7 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
         } else {
           if (run_n) {
             HIPCHK(c, hipMemcpyAsync(run_d, run_h, run_n, hipMemcpyHostToDevice, c->copy_stream[c->copy_rr]));
-            c->copy_rr = (c->copy_rr + 1) % kCopyStreams;
+            c->copy_rr = (c->copy_rr + 1) % g_copy_used;
           }
           run_h = y ? y->up_host : nullptr;
           run_d = y ? y->up_dev : nullptr;
@@ -1240,7 +1249,7 @@ int reconstruct_core(hevcrecon_ctx *c, int n, hevcrecon_syntax *const *syn, cons
     bool wait = uploaded_any;
     for (int i = 0; i < n; i++) wait = wait || syn[i]->upload_seq > c->upload_waited;
     if (wait) {
-      for (int k = 0; k < kCopyStreams; k++) {
+      for (int k = 0; k < g_copy_used; k++) {
         hipEvent_t e = c->copy_ev[c->copy_ev_pos * kCopyStreams + k];
         HIPCHK(c, hipEventRecord(e, c->copy_stream[k]));
         HIPCHK(c, hipStreamWaitEvent(c->stream, e, 0));

@@ -301,8 +301,8 @@ void hevcrecon_hub_disconnect(hevcrecon_hub *hub);
  * (hevcrecon_syntax_finish marks it once): for hosts that keep packed pictures around, and for measuring the
  * hand-over.  The pictures of a batch that are so marked cross the host link when the batch is submitted: copy
  * commands from their pinned staging (pictures that lie back to back in the context's upload ring share one command,
- * cut into pieces of a few megabytes) spread over three copy streams that the contexts of a device share, beside
- * the kernels of the batches queued before; the batch's kernels wait for them once. */
+ * cut into pieces of a few megabytes) on a copy stream that the contexts of a device share, beside the kernels of
+ * the batches queued before; the batch's kernels wait for them once. */
 int hevcrecon_syntax_upload(hevcrecon_syntax *syn);
 int hevcrecon_syntax_upload_batch(int n, hevcrecon_syntax *const *syn);
 

@@ -3,11 +3,12 @@
 import collections
 import csv
 import glob
+import os
 import sys
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 for p in sorted(glob.glob(root + "/p*/")):
-    fs = glob.glob(p + "*/*counter_collection.csv")
+    fs = sorted(glob.glob(p + "*/*counter_collection.csv"), key=os.path.getmtime)[-1:]  # the newest run of the pass
     if not fs:
         continue
     agg = collections.defaultdict(lambda: collections.defaultdict(float))

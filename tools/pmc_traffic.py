@@ -16,6 +16,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
 
@@ -25,7 +26,8 @@ target = sys.argv[5] if len(sys.argv) > 5 else None
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(lambda: collections.defaultdict(set))
 for p in ("p1", "p3", "p4"):
-    for fn in glob.glob("%s/%s/*/*counter_collection.csv" % (root, p)):
+    # (the newest file of a pass: results merged back from several runs may lie side by side)
+    for fn in sorted(glob.glob("%s/%s/*/*counter_collection.csv" % (root, p)), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(fn)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
