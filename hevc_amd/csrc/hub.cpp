@@ -217,9 +217,12 @@ int main(int argc, char **argv) {
         }
       }
       // a client that has left: when everything of it has run, its pictures and its slot are free again
-      if (st == HR_HUB_CLOSING && c->consumed.load(std::memory_order_relaxed) == c->produced.load(std::memory_order_acquire) &&
-          batch_clients[k.cx].empty() /* nothing of it in this round */) {
+      if (st == HR_HUB_CLOSING && c->consumed.load(std::memory_order_relaxed) == c->produced.load(std::memory_order_acquire)) {
         bool pending = false;
+        if (k.cx) {  // a picture of it in this round's batch?
+          const std::vector<int> &in_round = batch_clients[k.cx];
+          for (size_t q = 0; q < in_round.size(); q++) pending = pending || in_round[q] == i;
+        }
         if (k.cx)
           for (size_t q = 0; q < k.cx->waiting.size(); q++) pending = pending || k.cx->waiting[q].second == i;
         for (size_t t = 0; t < tickets.size(); t++)
