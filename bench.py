@@ -72,8 +72,8 @@ def level_schedule(seq, window=8):
     """Batches of mutually independent pictures of ONE stream.  Parsing never reads samples, so a decoder can parse a
     group of pictures ahead and hand its pictures over by dependency level instead of one by one: of the random-access
     hierarchy's eight pictures per group (decoded 8 4 2 1 3 6 5 7) first 8, then 4, then 2 and 6, then 1 3 5 7, which
-    refer to nothing inside their batch (TLibCommon/TComSlice.cpp:450-465 builds the lists; SURVEY of the dependencies
-    in the cfg: cfg/encoder_randomaccess_main.cfg:29-36).  The first picture stands alone; after it, windows of `window`
+    refer to nothing inside their batch (TLibCommon/TComSlice.cpp:450-465 builds the lists; the dependencies are those
+    of the GOP table in cfg/encoder_randomaccess_main.cfg:29-36).  The first picture stands alone; after it, windows of `window`
     pictures in decoding order, inside a window a picture's level is one more than the highest level among its
     references in the window."""
     refs = reference_indices(seq)
